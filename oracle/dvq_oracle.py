@@ -1,0 +1,377 @@
+"""CPU oracle for the D-VQVAE grasp-generation hot path.
+
+THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  It restates, op for op and in
+fp32 on the CPU, what the reference's PyTorch modules compute for the path
+  PointNet encoder -> VQ nearest-codebook argmin -> decoder -> MANO skinning
+so that the HIP kernels can be checked against it.  Only tests/, the smoke check
+and the cpu_baseline leg of the benchmark may import it; nothing shipped routes
+through it.
+
+It is written as plain functions over a flat ``state_dict`` (name -> tensor) so it
+needs none of the reference's classes at run time.  Pinned against the reference
+itself (imported on CPU in the build container) by tests/golden/make_golden.py;
+the captured vectors live in tests/golden/*.npz and tests/test_oracle_golden.py
+replays them.
+
+Reference citations (paths relative to the reference checkout):
+  VQ          DVQ-VAE/network/vqvae/quantizer.py:30-54, 68-75
+  PointNet    DVQ-VAE/network/pointnet_encoder.py:27-45 (STN3d), 140-169 (encoder)
+  MLP heads   DVQ-VAE/network/DVQVAE.py:145-185
+  gen()       DVQ-VAE/network/gen_net.py:78-125
+  DVQVAE eval DVQ-VAE/network/DVQVAE.py:42-98, 130-142
+  prior       DVQ-VAE/network/pixelcnn/models.py:21-88, 130-198
+  MANO        DVQ-VAE-2/MANO-master/mano/model.py:311-359, mano/lbs.py:33-265
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+BN_EPS = 1e-5  # torch.nn.BatchNorm1d default, used by every BN on the path
+
+# Kinematic tree of the MANO hand (kintree_table[0] with the root set to -1,
+# mano/model.py:232-233).
+MANO_PARENTS = (-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14)
+
+# Grid cells of the 3x3 prior sample that hold the six part indices
+# (gen_net.py:95-100): (row, col) for part 0..5.
+PART_CELLS = ((0, 1), (0, 2), (1, 1), (1, 2), (2, 1), (2, 2))
+
+
+# --------------------------------------------------------------------------- VQ
+def vq_distances(z: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
+    """quantizer.py:46-48: d = (sum z^2 + sum E^2) - 2 z E^T, evaluated in that order."""
+    zf = z.reshape(-1, E.shape[1])
+    return torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(E ** 2, dim=1) \
+        - 2 * torch.matmul(zf, E.t())
+
+
+def vq_forward(z: torch.Tensor, E: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """quantizer.py:44-54 (istrain=False): returns (idx int64 [n,1], z_q of z.shape).
+
+    Includes the one-hot scatter + matmul the reference uses to fetch the rows."""
+    d = vq_distances(z, E)
+    idx = torch.argmin(d, dim=1).unsqueeze(1)
+    onehot = torch.zeros(idx.shape[0], E.shape[0])
+    onehot.scatter_(1, idx, 1)
+    z_q = torch.matmul(onehot, E).view(z.shape)
+    return idx, z_q
+
+
+def vq_get_emb(idx: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
+    """quantizer.py:68-75 generalised to a batch: row b equals the reference's
+    get_emb(idx[b:b+1], dim) (the reference only accepts one index per call)."""
+    idx = idx.reshape(-1, 1).to(torch.int64)
+    onehot = torch.zeros(idx.shape[0], E.shape[0])
+    onehot.scatter_(1, idx, 1)
+    return torch.matmul(onehot, E)
+
+
+def vq_gap_fp64(z: np.ndarray, E: np.ndarray, chunk: int = 4096):
+    """Exact (fp64) squared distances: per row the best index, the best distance and
+    the best-vs-second gap.  Used to decide which rows are near-ties."""
+    z = np.asarray(z, dtype=np.float64)
+    E = np.asarray(E, dtype=np.float64)
+    e2 = (E * E).sum(1)
+    best = np.empty(z.shape[0], np.int64)
+    dmin = np.empty(z.shape[0], np.float64)
+    gap = np.empty(z.shape[0], np.float64)
+    for s in range(0, z.shape[0], chunk):
+        zz = z[s:s + chunk]
+        d = (zz * zz).sum(1, keepdims=True) + e2[None, :] - 2.0 * zz @ E.T
+        b = d.argmin(1)
+        part = np.partition(d, 1, axis=1) if d.shape[1] > 1 else np.concatenate([d, d + np.inf], 1)
+        best[s:s + chunk] = b
+        dmin[s:s + chunk] = part[:, 0]
+        gap[s:s + chunk] = part[:, 1] - part[:, 0]
+    return best, dmin, gap
+
+
+def vq_dist_fp64_at(z: np.ndarray, E: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """fp64 squared distance of row i to code idx[i]."""
+    z = np.asarray(z, dtype=np.float64)
+    e = np.asarray(E, dtype=np.float64)[np.asarray(idx).reshape(-1)]
+    return ((z - e) ** 2).sum(1)
+
+
+def vq_tau(z: np.ndarray, E: np.ndarray, ulps: float = 4.0) -> np.ndarray:
+    """Near-tie threshold per row: `ulps` fp32 ulps of (|z|^2 + max|E|^2), the magnitude
+    at which the reference rounds its distances before the argmin."""
+    z = np.asarray(z, dtype=np.float64)
+    E = np.asarray(E, dtype=np.float64)
+    mag = (z * z).sum(1) + (E * E).sum(1).max()
+    return ulps * np.spacing(mag.astype(np.float32)).astype(np.float64)
+
+
+# --------------------------------------------------------------------- PointNet
+def _conv_bn(x, sd: SD, conv: str, bn: str, relu: bool):
+    """Conv1d(k=1) + BatchNorm1d(eval) (+ReLU) on x [B,C,N]."""
+    y = F.conv1d(x, sd[conv + ".weight"], sd[conv + ".bias"])
+    y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"],
+                     sd[bn + ".weight"], sd[bn + ".bias"], False, 0.0, BN_EPS)
+    return F.relu(y) if relu else y
+
+
+def _fc_bn(x, sd: SD, fc: str, bn: Optional[str], relu: bool):
+    y = F.linear(x, sd[fc + ".weight"], sd[fc + ".bias"])
+    if bn is not None:
+        y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"],
+                         sd[bn + ".weight"], sd[bn + ".bias"], False, 0.0, BN_EPS)
+    return F.relu(y) if relu else y
+
+
+def stn3d(x: torch.Tensor, sd: SD, p: str) -> torch.Tensor:
+    """pointnet_encoder.py:27-45.  x [B,C,N] -> trans [B,3,3].  `p` is the key prefix
+    of the STN3d module, e.g. 'obj_encoder_type.stn.'."""
+    B = x.shape[0]
+    h = _conv_bn(x, sd, p + "conv1", p + "bn1", True)
+    h = _conv_bn(h, sd, p + "conv2", p + "bn2", True)
+    h = _conv_bn(h, sd, p + "conv3", p + "bn3", True)
+    h = torch.max(h, 2, keepdim=True)[0].view(-1, 1024)
+    h = _fc_bn(h, sd, p + "fc1", p + "bn4", True)
+    h = _fc_bn(h, sd, p + "fc2", p + "bn5", True)
+    h = _fc_bn(h, sd, p + "fc3", None, False)
+    iden = torch.eye(3, dtype=torch.float32).view(1, 9).repeat(B, 1)
+    return (h + iden).view(-1, 3, 3)
+
+
+def pointnet_encoder(x: torch.Tensor, sd: SD, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pointnet_encoder.py:140-169 with global_feat=True, feature_transform=False.
+    x [B,D,N] -> (feat [B,1024], trans [B,3,3])."""
+    B, D, N = x.shape
+    trans = stn3d(x, sd, p + "stn.")
+    pts = x.transpose(2, 1)
+    if D > 3:
+        xyz, extra = pts[:, :, :3], pts[:, :, 3:]
+    else:
+        xyz, extra = pts, None
+    xyz = torch.bmm(xyz, trans)
+    pts = torch.cat([xyz, extra], dim=2) if extra is not None else xyz
+    h = pts.transpose(2, 1)
+    h = _conv_bn(h, sd, p + "conv1", p + "bn1", True)
+    h = _conv_bn(h, sd, p + "conv2", p + "bn2", True)
+    h = _conv_bn(h, sd, p + "conv3", p + "bn3", False)
+    feat = torch.max(h, 2, keepdim=True)[0].view(-1, 1024)
+    return feat, trans
+
+
+# -------------------------------------------------------------------- MLP heads
+def decoder_mlp(x: torch.Tensor, sd: SD, p: str, n_layers: int = 3) -> torch.Tensor:
+    """DVQVAE.py:169-185: Linear+ReLU ... Linear (no activation after the last)."""
+    for i in range(n_layers):
+        x = F.linear(x, sd[f"{p}MLP.L{i}.weight"], sd[f"{p}MLP.L{i}.bias"])
+        if i + 1 < n_layers:
+            x = F.relu(x)
+    return x
+
+
+def part_latent_mlp(x: torch.Tensor, sd: SD, p: str) -> torch.Tensor:
+    """DVQVAE.py:145-166 with layer_sizes=[1024,512]: Linear+ReLU then linear_means."""
+    x = F.relu(F.linear(x, sd[p + "MLP.L0.weight"], sd[p + "MLP.L0.bias"]))
+    return F.linear(x, sd[p + "linear_means.weight"], sd[p + "linear_means.bias"])
+
+
+# ------------------------------------------------------------------------- MANO
+def batch_rodrigues(rot_vecs: torch.Tensor) -> torch.Tensor:
+    """lbs.py:167-198 (note the +1e-8 inside the norm, lbs.py:182)."""
+    n = rot_vecs.shape[0]
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos = torch.cos(angle).unsqueeze(1)
+    sin = torch.sin(angle).unsqueeze(1)
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros((n, 1), dtype=rot_vecs.dtype)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(n, 3, 3)
+    ident = torch.eye(3, dtype=rot_vecs.dtype).unsqueeze(0)
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def _rigid_chain(rot_mats, joints, parents):
+    """lbs.py:214-265."""
+    joints = joints.unsqueeze(-1)
+    rel = joints.clone()
+    par = torch.as_tensor(parents[1:], dtype=torch.long)
+    rel[:, 1:] -= joints[:, par]
+    R = rot_mats.reshape(-1, 3, 3)
+    t = rel.reshape(-1, 3, 1)
+    M = torch.cat([F.pad(R, [0, 0, 0, 1]), F.pad(t, [0, 0, 0, 1], value=1)], dim=2)
+    M = M.reshape(-1, joints.shape[1], 4, 4)
+    chain = [M[:, 0]]
+    for i in range(1, len(parents)):
+        chain.append(torch.matmul(chain[parents[i]], M[:, i]))
+    T = torch.stack(chain, dim=1)
+    posed = T[:, :, :3, 3]
+    jh = F.pad(joints, [0, 0, 0, 1])
+    A = T - F.pad(torch.matmul(T, jh), [3, 0, 0, 0, 0, 0, 0, 0])
+    return posed, A
+
+
+def mano_forward(sd: SD, global_orient: torch.Tensor, hand_pose: torch.Tensor,
+                 transl: Optional[torch.Tensor], p: str = ""):
+    """model.py:311-359 + lbs.py:33-120 for use_pca=True, pose2rot=True.
+
+    The reference passes the module's own all-zero `betas` parameter to lbs
+    (model.py:335), so the shape term is identically zero and the `betas`
+    argument of the call has no effect; that is reproduced here by not taking one.
+    Returns (vertices [B,778,3], joints [B,16,3], full_pose [B,48])."""
+    B = hand_pose.shape[0]
+    v_template = sd[p + "v_template"]
+    shapedirs = sd[p + "shapedirs"]
+    posedirs = sd[p + "posedirs"]
+    J_regressor = sd[p + "J_regressor"]
+    W = sd[p + "lbs_weights"]
+    comps = sd[p + "hand_components"]
+    pose_mean = sd[p + "pose_mean"]
+    parents = [int(v) for v in sd[p + "parents"].tolist()]
+
+    pose = torch.einsum("bi,ij->bj", hand_pose, comps)
+    full_pose = torch.cat([global_orient, pose], dim=1) + pose_mean
+    betas = torch.zeros(B, shapedirs.shape[-1], dtype=torch.float32)
+    v_shaped = v_template + torch.einsum("bl,mkl->bmk", betas, shapedirs)
+    J = torch.einsum("bik,ji->bjk", v_shaped, J_regressor)
+    rot = batch_rodrigues(full_pose.view(-1, 3)).view(B, -1, 3, 3)
+    ident = torch.eye(3, dtype=torch.float32)
+    pose_feature = (rot[:, 1:] - ident).view(B, -1)
+    v_posed = torch.matmul(pose_feature, posedirs).view(B, -1, 3) + v_shaped
+    Jt, A = _rigid_chain(rot, J, parents)
+    nj = J_regressor.shape[0]
+    T = torch.matmul(W.unsqueeze(0).expand(B, -1, -1), A.view(B, nj, 16)).view(B, -1, 4, 4)
+    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1)], dim=2)
+    verts = torch.matmul(T, vh.unsqueeze(-1))[:, :, :3, 0]
+    if transl is not None:
+        Jt = Jt + transl.unsqueeze(1)
+        verts = verts + transl.unsqueeze(1)
+    return verts, Jt, full_pose
+
+
+# ------------------------------------------------------------------------ prior
+def _gate(x):
+    a, b = x.chunk(2, dim=1)
+    return torch.tanh(a) * torch.sigmoid(b)
+
+
+def pixelcnn_logits(sd: SD, x: torch.Tensor, label: torch.Tensor, p: str = "GatedPixelCNN.",
+                    n_layers: int = 15) -> torch.Tensor:
+    """pixelcnn/models.py:161-174 with the gated layers of :65-88.
+    x int64 [B,H,W], label int64 [B] -> logits [B, input_dim, H, W].
+    Layer 0 is mask 'A' (kernel 5, last kernel row/column zeroed, no residual);
+    the others are mask 'B' (kernel 3, residual)."""
+    h0 = F.embedding(x.reshape(-1), sd[p + "embedding.weight"]).view(*x.shape, -1)
+    h0 = h0.permute(0, 3, 1, 2)
+    xv = xh = h0
+    for i in range(n_layers):
+        lp = f"{p}layers.{i}."
+        k = 5 if i == 0 else 3
+        wv = sd[lp + "vert_stack.weight"]
+        wh = sd[lp + "horiz_stack.weight"]
+        if i == 0:
+            wv = wv.clone(); wv[:, :, -1] = 0
+            wh = wh.clone(); wh[:, :, :, -1] = 0
+        h = F.embedding(label, sd[lp + "class_cond_embedding.weight"])
+        hv = F.conv2d(xv, wv, sd[lp + "vert_stack.bias"], 1, (k // 2, k // 2))
+        hv = hv[:, :, :xv.size(-1), :]
+        out_v = _gate(hv + h[:, :, None, None])
+        hh = F.conv2d(xh, wh, sd[lp + "horiz_stack.bias"], 1, (0, k // 2))
+        hh = hh[:, :, :, :xh.size(-2)]
+        v2h = F.conv2d(hv, sd[lp + "vert_to_horiz.weight"], sd[lp + "vert_to_horiz.bias"])
+        out = _gate(v2h + hh + h[:, :, None, None])
+        res = F.conv2d(out, sd[lp + "horiz_resid.weight"], sd[lp + "horiz_resid.bias"])
+        xh = res + xh if i > 0 else res
+        xv = out_v
+    y = F.conv2d(xh, sd[p + "output_conv.0.weight"], sd[p + "output_conv.0.bias"])
+    y = F.relu(y)
+    return F.conv2d(y, sd[p + "output_conv.2.weight"], sd[p + "output_conv.2.bias"])
+
+
+def pixelcnn_generate(sd: SD, label: torch.Tensor, shape=(3, 3), forced: Optional[torch.Tensor] = None,
+                      generator: Optional[torch.Generator] = None, p: str = "GatedPixelCNN."):
+    """pixelcnn/models.py:176-198: H*W sequential full forwards; cell (i,j) is sampled
+    from softmax(logits[:, :, i, j]).  With `forced` (int64 [B,H,W]) the sample is
+    replaced by the given index (teacher forcing) so results do not depend on an RNG.
+    Returns (x int64 [B,H,W], probs float32 [B,H,W,classes]) where probs[b,i,j] is the
+    per-row distribution cell (i,j) was drawn from (the reference's extra division by
+    probs.sum() is the identity at its only supported batch size of 1 and is applied
+    per row here)."""
+    B = label.shape[0]
+    x = torch.zeros((B, *shape), dtype=torch.int64)
+    all_probs = []
+    for i in range(shape[0]):
+        for j in range(shape[1]):
+            logits = pixelcnn_logits(sd, x, label, p)
+            probs = F.softmax(logits[:, :, i, j], -1)
+            probs = probs / probs.sum(dim=1, keepdim=True)
+            all_probs.append(probs)
+            if forced is not None:
+                x[:, i, j] = forced[:, i, j]
+            else:
+                x[:, i, j] = probs.multinomial(1, generator=generator).squeeze(1)
+    return x, torch.stack(all_probs, 1).view(B, shape[0], shape[1], -1)
+
+
+# ------------------------------------------------------------------- generation
+def gen(sd: SD, obj: torch.Tensor, x_tilde: Optional[torch.Tensor] = None,
+        generator: Optional[torch.Generator] = None, mano_prefix: str = "rh_mano."):
+    """gen_net.py:78-125, batched (row b equals the reference run on obj[b:b+1]).
+
+    x_tilde (int64 [B,3,3]) teacher-forces the prior sample; when None the prior is
+    sampled with `generator`.  Returns a dict with every intermediate a test may want."""
+    B = obj.shape[0]
+    f_type, trans_type = pointnet_encoder(obj, sd, "obj_encoder_type.")
+    f_pos, trans_pos = pointnet_encoder(obj, sd, "obj_encoder_pos.")
+    idx6, obj_emb = vq_forward(f_type, sd["vqvae6.vector_quantization.embedding.weight"])
+    label = idx6[:, 0]
+    if x_tilde is None:
+        x_tilde, _ = pixelcnn_generate(sd, label, (3, 3), None, generator)
+    embs = []
+    for k, (r, c) in enumerate(PART_CELLS):
+        embs.append(vq_get_emb(x_tilde[:, r, c], sd[f"vqvae{k}.vector_quantization.embedding.weight"]))
+    z_out = torch.cat(embs + [f_type], dim=1)
+    recon = decoder_mlp(z_out, sd, "decoder.").contiguous().view(B, 55)
+    zero3 = torch.zeros(B, 3)
+    verts0, _, _ = mano_forward(sd, zero3, recon[:, 10:55], zero3, mano_prefix)
+    f_hand, _ = pointnet_encoder(verts0.permute(0, 2, 1), sd, "recon_encoder.")
+    pos = decoder_mlp(torch.cat([f_hand, f_pos], dim=1), sd, "pos_decoder.").contiguous().view(B, 6)
+    return dict(recon=recon, recon_pos=pos, idx6=idx6, obj_emb=obj_emb, x_tilde=x_tilde,
+                feat_type=f_type, feat_pos=f_pos, trans_type=trans_type, trans_pos=trans_pos,
+                verts0=verts0, feat_hand=f_hand)
+
+
+def assemble_param(recon: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """gen_diverse_grasp_obman.py:243-247: [betas10 | rot3 | pose45 | transl3]."""
+    B = recon.shape[0]
+    out = torch.zeros(B, 61)
+    out[:, 0:10] = recon[:, 0:10]
+    out[:, 10:13] = pos[:, 0:3]
+    out[:, 13:58] = recon[:, 10:55]
+    out[:, 58:61] = pos[:, 3:6]
+    return out
+
+
+def generate_grasps(sd: SD, obj: torch.Tensor, x_tilde=None, generator=None, mano_prefix="rh_mano."):
+    """gen() followed by the call-site MANO (gen_diverse_grasp_obman.py:236-253):
+    one object cloud in, one [778,3] hand out."""
+    g = gen(sd, obj, x_tilde, generator, mano_prefix)
+    param = assemble_param(g["recon"], g["recon_pos"])
+    verts, joints, _ = mano_forward(sd, param[:, 10:13], param[:, 13:58], param[:, 58:61], mano_prefix)
+    g.update(recon_param=param, vertices=verts, joints=joints)
+    return g
+
+
+def dvqvae_eval(sd: SD, obj_pc: torch.Tensor, hand_xyz: torch.Tensor, part_indices: Sequence[Sequence[int]]):
+    """DVQVAE.py:42-98,130-142 (eval branch).  part_indices = [f0,f1,f2,f3,f4,palm] vertex
+    lists.  Returns (emb_idx int64 [7B,1] codebook-major: object first, obj_emb [B,1024])."""
+    hand = hand_xyz - hand_xyz.mean(dim=2).unsqueeze(2).repeat(1, 1, hand_xyz.shape[2])
+    f_type, _ = pointnet_encoder(obj_pc, sd, "obj_encoder_type.")
+    idxs = []
+    for k, ids in enumerate(part_indices):
+        feat, _ = pointnet_encoder(hand[:, :, list(ids)], sd, f"fing_{k}.")
+        lat = part_latent_mlp(feat, sd, f"emb_{k}.")
+        i_k, _ = vq_forward(lat, sd[f"vqvae{k}.vector_quantization.embedding.weight"])
+        idxs.append(i_k)
+    idx6, obj_emb = vq_forward(f_type, sd["vqvae6.vector_quantization.embedding.weight"])
+    return torch.cat([idx6] + idxs, 0), obj_emb
