@@ -1,0 +1,39 @@
+// Shared helpers for the libdvq_hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dvq_hip.h"
+
+namespace dvq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;
+
+// Per-thread error text returned by dvq_last_error().
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+// Checks the launch that was just enqueued.
+int check_launch(const char* what);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// round-to-nearest-even fp32 -> bf16 bits (NaN kept a NaN by the hardware convert)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    __bf16 b = static_cast<__bf16>(f);
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) {
+    return __builtin_bit_cast(float, static_cast<unsigned int>(u) << 16);
+}
+
+}  // namespace dvq

@@ -1,0 +1,164 @@
+// fp32 linear layers on the matrix cores and the BatchNorm fold (gfx950).
+//
+// dvq_linear replaces the nn.Linear (+ReLU) stacks of the reference: the STN head
+// (DVQ-VAE/network/pointnet_encoder.py:35-43) and Encoder/Decoder
+// (DVQ-VAE/network/DVQVAE.py:161-185).  y = act(x W^T + b), exact fp32: the
+// 32x32x2 f32 MFMA is a k-ordered fmaf chain.
+//
+// Both operands are k-contiguous ([M,K] and [N,K]), so every lane loads 16 contiguous
+// bytes of its own row for x and for W; the k order inside a group of 8 is permuted
+// the same way for both (lane half h takes k0+4h..k0+4h+3), which a contraction does
+// not care about.  One wave produces one 32x32 output tile.  Batches of up to 16 rows
+// (the reference runs B=1) take a different kernel: one wave per output column streams
+// that weight row with all 64 lanes along k and reduces across lanes, so the weight
+// matrix is read once, coalesced, by N waves, and results do not depend on arrival order.
+#include "common.h"
+
+namespace dvq {
+
+constexpr int kLinWaves = 4;
+
+__global__ __launch_bounds__(kLinWaves * 64) void linear_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, const float* __restrict__ bias, int M, int K,
+    int N, int relu, int add_id3, float* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+    const int n_tiles_n = (N + 31) / 32;
+    const int tile = blockIdx.x * kLinWaves + wave;
+    const int tm = tile / n_tiles_n;
+    const int tn = tile % n_tiles_n;
+    if (tm * 32 >= M) return;
+    int rowx = tm * 32 + r; if (rowx >= M) rowx = M - 1;
+    int roww = tn * 32 + r; if (roww >= N) roww = N - 1;
+    const float* xp = x + (int64_t)rowx * ldx;
+    const float* wp = W + (int64_t)roww * K;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    int k0 = 0;
+    const int k_vec_end = (K / 8) * 8;
+#pragma unroll 4
+    for (; k0 < k_vec_end; k0 += 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k0 + 4 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(wp + k0 + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 2) {  // tail: natural order, zero beyond K
+        const int k = k0 + h;
+        const float a = k < K ? xp[k] : 0.f;
+        const float b = k < K ? wp[k] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    const int col = tn * 32 + r;
+    if (col >= N) return;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < M) {
+            float v = acc[i] + bv;
+            if (relu) v = v > 0.f ? v : 0.f;
+            if (add_id3 && (col % 4) == 0) v += 1.f;
+            y[(int64_t)row * ldy + col] = v;
+        }
+    }
+}
+
+// M <= kSkinnyM rows: one wave per output column.
+constexpr int kSkinnyM = 16;
+template <int MR>
+__global__ __launch_bounds__(256) void linear_skinny_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, const float* __restrict__ bias, int M, int K,
+    int N, int relu, int add_id3, float* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= N) return;
+    const float* wp = W + (int64_t)col * K;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + k);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int mm = m < M ? m : M - 1;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + (int64_t)mm * ldx + k);
+            acc[m] = __builtin_fmaf(a[0], w[0], acc[m]);
+            acc[m] = __builtin_fmaf(a[1], w[1], acc[m]);
+            acc[m] = __builtin_fmaf(a[2], w[2], acc[m]);
+            acc[m] = __builtin_fmaf(a[3], w[3], acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        float v = acc[m];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        acc[m] = v;
+    }
+    if (lane == 0) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < M) {
+                float v = acc[m] + bv;
+                if (relu) v = v > 0.f ? v : 0.f;
+                if (add_id3 && (col % 4) == 0) v += 1.f;
+                y[(int64_t)m * ldy + col] = v;
+            }
+        }
+    }
+}
+
+__global__ void fold_bn_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
+                               float eps, int out_f, int in_f, float* __restrict__ A, float* __restrict__ c) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)out_f * in_f) return;
+    const int o = (int)(t / in_f);
+    const float s = gamma[o] / sqrtf(var[o] + eps);
+    A[t] = s * W[t];
+    if (t % in_f == 0) c[o] = __builtin_fmaf(s, b[o] - mean[o], beta[o]);
+}
+
+}  // namespace dvq
+
+using namespace dvq;
+
+extern "C" int dvq_linear(const float* x, int64_t ldx, const float* W, const float* b, int M, int K, int N, int relu,
+                          int add_identity3, float* y, int64_t ldy, void* stream) {
+    if (M < 0 || K < 1 || N < 1) return fail(DVQ_EINVAL, "linear: bad shape M=%d K=%d N=%d", M, K, N);
+    if (M == 0) return DVQ_OK;
+    if (!x || !W || !y) return fail(DVQ_EINVAL, "linear: null pointer");
+    if (ldx < K || ldy < N) return fail(DVQ_EINVAL, "linear: row stride smaller than the row");
+    if ((K % 4) != 0 || (ldx % 4) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)W & 15))
+        return fail(DVQ_EINVAL, "linear: K and ldx must be multiples of 4 and x, W 16-byte aligned");
+    if (add_identity3 && N != 9) return fail(DVQ_EINVAL, "linear: add_identity3 needs a 9-wide output");
+    hipStream_t st = as_stream(stream);
+    if (M <= kSkinnyM) {
+        const int grid = (N + 3) / 4;
+        if (M <= 4)
+            hipLaunchKernelGGL((linear_skinny_kernel<4>), dim3(grid), dim3(256), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy);
+        else
+            hipLaunchKernelGGL((linear_skinny_kernel<kSkinnyM>), dim3(grid), dim3(256), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy);
+    } else {
+        const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+        const int blocks = (tiles + kLinWaves - 1) / kLinWaves;
+        hipLaunchKernelGGL(linear_kernel, dim3(blocks), dim3(kLinWaves * 64), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy);
+    }
+    return check_launch("linear");
+}
+
+extern "C" int dvq_fold_bn(const float* W, const float* b, const float* gamma, const float* beta, const float* mean,
+                           const float* var, float eps, int out_f, int in_f, float* A, float* c, void* stream) {
+    if (out_f < 1 || in_f < 1) return fail(DVQ_EINVAL, "fold_bn: bad shape");
+    if (!W || !b || !gamma || !beta || !mean || !var || !A || !c) return fail(DVQ_EINVAL, "fold_bn: null pointer");
+    const int64_t total = (int64_t)out_f * in_f;
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), W, b, gamma, beta, mean,
+                       var, eps, out_f, in_f, A, c);
+    return check_launch("fold_bn");
+}

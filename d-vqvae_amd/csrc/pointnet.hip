@@ -1,0 +1,372 @@
+// PointNet shared per-point MLP (C -> 64 -> 128 -> 1024) + global max-pool, fused (gfx950).
+//
+// Replaces the Conv1d(k=1)+BatchNorm(+ReLU) x3 + torch.max of STN3d.forward and
+// PointNetEncoder.forward (DVQ-VAE/network/pointnet_encoder.py:29-33, 146-164).  The
+// reference materialises [B,64,N], [B,128,N] and [B,1024,N] activations; here a point's
+// activations never leave the register file:
+//
+//   conv1 (C<=4 inputs)   fp32 VALU; a lane computes 32 of the 64 channels of ITS point,
+//                         already in the layout of an MFMA B operand.
+//   conv2 (64 -> 128)     MFMA with the weights as A (rows = output channel) and the
+//                         points as B (columns = point): the 32x32 accumulator then has
+//                         the POINT on the lane and the channel in the registers.
+//   conv3 (128 -> 1024)   that accumulator, after bias/ReLU (and bf16 packing), is used
+//                         AS IS as the A operand of the next MFMA (an accumulator tile
+//                         X used as A computes X^T * B), with the conv3 weights as B
+//                         (columns = output channel).  Its result has the point in the
+//                         registers and the output channel on the lane, so
+//   max over points       is a lane-local max over registers; one shuffle merges the
+//                         two half-waves and one LDS atomic per (wave, 32 channels)
+//                         folds it into the block's running maximum.
+//
+// One workgroup (8 waves) walks one cloud in chunks of 8*NP*32 points.  The conv3
+// weights (256 KiB bf16 / 512 KiB fp32, pre-packed in fragment order) stream through a
+// double-buffered LDS stage by direct global->LDS loads while the matrix cores work on
+// the previous stage; conv1/conv2 weights stay resident in LDS.  HBM traffic is the
+// input cloud once (16 B per point) and 4 KiB of output per cloud.
+#include "common.h"
+
+namespace dvq {
+
+constexpr int kPnWaves = 8;
+constexpr int kPnThreads = kPnWaves * 64;
+constexpr int kC1 = 64, kC2 = 128, kC3 = 1024;
+constexpr int kCt = kC3 / 32;  // 32 output-channel tiles
+
+template <int DT> struct PnCfg;
+template <> struct PnCfg<DVQ_BF16> {
+    static constexpr int NP = 4;          // 32-point tiles per wave and chunk
+    static constexpr int UPC = 8;         // 1-KiB conv3 weight units per channel tile (4 row tiles x 2 k-steps)
+    static constexpr int CPS = 8;         // channel tiles per LDS stage (64 KiB)
+    static constexpr int A2_UNITS = 16;   // conv2 weights: 4 row tiles x 4 k-steps
+    static constexpr int XR = 8;          // 4-register groups of conv2 output per point tile (8 frags x 4 VGPRs)
+};
+template <> struct PnCfg<DVQ_F32> {
+    static constexpr int NP = 2;
+    static constexpr int UPC = 16;        // 4 row tiles x 4 groups of 4 k-steps
+    static constexpr int CPS = 2;         // 32 KiB per stage
+    static constexpr int A2_UNITS = 32;   // 4 row tiles x 8 groups of 4 k-steps
+    static constexpr int XR = 16;
+};
+
+// Order-preserving float <-> int map so that an integer max is a float max.
+__device__ __forceinline__ int f32_key(float f) {
+    const int b = __builtin_bit_cast(int, f);
+    return b >= 0 ? b : (b ^ 0x7FFFFFFF);
+}
+__device__ __forceinline__ float key_f32(int k) {
+    return __builtin_bit_cast(float, k >= 0 ? k : (k ^ 0x7FFFFFFF));
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {
+    // 64 lanes x 16 B: lane l's bytes land at lds_wave_base + 16*l
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// conv3 weights [1024,128] fp32 -> fragment order for `DT`.
+//   bf16 unit (ct, t2, s): lane (c,h) holds 8 bf16: j -> A3[32ct+c][32t2 + 16s + 8(j>>2) + 4h + (j&3)]
+//   fp32 unit (ct, t2, g): lane (c,h) holds 4 f32 : q -> A3[32ct+c][32t2 + 8g + 4h + q]
+// (the k order an accumulator tile presents when it is reused as an MFMA A operand).
+template <int DT>
+__global__ void pn_pack_w3_kernel(const float* __restrict__ a3, uint4* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = kCt * PnCfg<DT>::UPC * 64;
+    if (t >= total) return;
+    const int l = t & 63, unit = t >> 6;
+    const int c = l & 31, h = l >> 5;
+    const int ct = unit / PnCfg<DT>::UPC, u = unit % PnCfg<DT>::UPC;
+    const float* row = a3 + (ct * 32 + c) * kC2;
+    uint4 v;
+    if (DT == DVQ_BF16) {
+        const int t2 = u >> 1, s = u & 1;
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16_bits(row[32 * t2 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)]);
+        v.x = e[0] | (e[1] << 16); v.y = e[2] | (e[3] << 16); v.z = e[4] | (e[5] << 16); v.w = e[6] | (e[7] << 16);
+    } else {
+        const int t2 = u >> 2, g = u & 3;
+        v = *reinterpret_cast<const uint4*>(row + 32 * t2 + 8 * g + 4 * h);
+    }
+    out[t] = v;
+}
+
+template <int DT, int C>
+__global__ __launch_bounds__(kPnThreads) void pointnet_mlp_max_kernel(
+    const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
+    const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat) {
+    typedef PnCfg<DT> Cfg;
+    constexpr int NP = Cfg::NP;
+    constexpr int STAGE_BYTES = Cfg::CPS * Cfg::UPC * 1024;
+    constexpr int N_STAGES = kCt / Cfg::CPS;
+    constexpr int A2_BYTES = Cfg::A2_UNITS * 1024;
+    constexpr int PTS_PER_CHUNK = kPnWaves * NP * 32;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* w3s = smem;                                                         // [2][STAGE_BYTES]
+    char* a2s = smem + 2 * STAGE_BYTES;                                       // conv2 weights, fragment order
+    float* a1s = reinterpret_cast<float*>(a2s + A2_BYTES);                    // [64][4]
+    float* c1s = a1s + kC1 * 4;                                               // [64]
+    float* c2s = c1s + kC1;                                                   // [128]
+    int* bmax = reinterpret_cast<int*>(c2s + kC2);                            // [1024] running max (int keys)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+    const int b = blockIdx.x;
+
+    // ---- resident tables
+    for (int i = tid; i < kC1 * 4; i += kPnThreads) {
+        const int ch = i >> 2, c = i & 3;
+        a1s[i] = c < C ? a1[ch * C + c] : 0.f;
+    }
+    for (int i = tid; i < kC1; i += kPnThreads) c1s[i] = c1[i];
+    for (int i = tid; i < kC2; i += kPnThreads) c2s[i] = c2[i];
+    for (int i = tid; i < kC3; i += kPnThreads) bmax[i] = (int)0x80000000;
+    // conv2 weights A2 [128][64] -> A-operand fragment order.  Channel order along k is
+    // ch1(h, t) = 32h + t, the order conv1 leaves its outputs in.
+    for (int i = tid; i < Cfg::A2_UNITS * 64; i += kPnThreads) {
+        const int l = i & 63, u = i >> 6;
+        const int rr = l & 31, hh = l >> 5;
+        if (DT == DVQ_BF16) {
+            const int t2 = u >> 2, s = u & 3;
+            const float* src = a2 + (32 * t2 + rr) * kC1 + 32 * hh + 8 * s;
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16_bits(src[j]);
+            uint4 v;
+            v.x = e[0] | (e[1] << 16); v.y = e[2] | (e[3] << 16); v.z = e[4] | (e[5] << 16); v.w = e[6] | (e[7] << 16);
+            *reinterpret_cast<uint4*>(a2s + i * 16) = v;
+        } else {
+            const int t2 = u >> 3, t4 = u & 7;
+            *reinterpret_cast<uint4*>(a2s + i * 16) =
+                *reinterpret_cast<const uint4*>(a2 + (32 * t2 + rr) * kC1 + 32 * hh + 4 * t4);
+        }
+    }
+    float T[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T[i] = trans ? trans[b * 9 + i] : ((i % 4) == 0 ? 1.f : 0.f);
+    const bool has_trans = trans != nullptr;
+    __syncthreads();
+
+    const float* xb = x + (int64_t)b * C * N;
+    const int n_chunks = (N + PTS_PER_CHUNK - 1) / PTS_PER_CHUNK;
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        // ---- kick off stage 0 of the conv3 weights; it lands while conv1/conv2 run
+        {
+            constexpr int UNITS = STAGE_BYTES / 1024;
+            for (int u = wave; u < UNITS; u += kPnWaves) glds16(w3p + (int64_t)u * 1024 + lane * 16, w3s + u * 1024);
+        }
+        // ---- conv1 + conv2 for this wave's NP point tiles -> X (conv3 A fragments)
+        bf16x8 Xb[(DT == DVQ_BF16) ? NP : 1][(DT == DVQ_BF16) ? 8 : 1];
+        float Xf[(DT == DVQ_F32) ? NP : 1][(DT == DVQ_F32) ? 64 : 1];
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            int n = chunk * PTS_PER_CHUNK + (wave * NP + np) * 32 + r;
+            if (n >= N) n = N - 1;  // duplicate the last point: a duplicate cannot change a max
+            float p[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = c < C ? xb[(int64_t)c * N + n] : 0.f;
+            if (has_trans) {  // xyz' = xyz * T  (pointnet_encoder.py:146)
+                const float q0 = p[0], q1 = p[1], q2 = p[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float v = q0 * T[j];
+                    v = __builtin_fmaf(q1, T[3 + j], v);
+                    v = __builtin_fmaf(q2, T[6 + j], v);
+                    p[j] = v;
+                }
+            }
+            // conv1: channels 32h .. 32h+31 of this lane's point
+            float h1[32];
+#pragma unroll
+            for (int t4 = 0; t4 < 8; ++t4) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(c1s + 32 * h + 4 * t4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(a1s + (32 * h + 4 * t4 + q) * 4);
+                    float v = w[0] * p[0];
+                    v = __builtin_fmaf(w[1], p[1], v);
+                    v = __builtin_fmaf(w[2], p[2], v);
+                    if (C > 3) v = __builtin_fmaf(w[3], p[3], v);
+                    v += bias[q];
+                    h1[4 * t4 + q] = v > 0.f ? v : 0.f;
+                }
+            }
+            if constexpr (DT == DVQ_BF16) {
+                bf16x8 hb[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hb[s][j] = static_cast<__bf16>(h1[8 * s + j]);
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(c2s + 32 * t2 + 8 * g + 4 * h);
+                        acc[4 * g + 0] = bias[0]; acc[4 * g + 1] = bias[1]; acc[4 * g + 2] = bias[2]; acc[4 * g + 3] = bias[3];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(a2s + ((t2 * 4 + s) * 64 + lane) * 16);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float v = acc[8 * s + j];
+                            Xb[np][t2 * 2 + s][j] = static_cast<__bf16>(v > 0.f ? v : 0.f);
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(c2s + 32 * t2 + 8 * g + 4 * h);
+                        acc[4 * g + 0] = bias[0]; acc[4 * g + 1] = bias[1]; acc[4 * g + 2] = bias[2]; acc[4 * g + 3] = bias[3];
+                    }
+#pragma unroll
+                    for (int t4 = 0; t4 < 8; ++t4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(a2s + ((t2 * 8 + t4) * 64 + lane) * 16);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], h1[4 * t4 + q], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float v = acc[i];
+                        Xf[np][t2 * 16 + i] = v > 0.f ? v : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // stage 0 has landed (the barrier drains the direct-to-LDS loads)
+
+        // ---- conv3 + max, one LDS stage of output-channel tiles at a time
+#pragma unroll 1
+        for (int st = 0; st < N_STAGES; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < N_STAGES) {
+                constexpr int UNITS = STAGE_BYTES / 1024;
+                const char* src = w3p + (int64_t)(st + 1) * STAGE_BYTES;
+                char* dst = w3s + (buf ^ 1) * STAGE_BYTES;
+                for (int u = wave; u < UNITS; u += kPnWaves) glds16(src + (int64_t)u * 1024 + lane * 16, dst + u * 1024);
+            }
+            const char* sb = w3s + buf * STAGE_BYTES + lane * 16;
+#pragma unroll 1
+            for (int cc = 0; cc < Cfg::CPS; ++cc) {
+                f32x16 acc[NP];
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[np][i] = 0.f;
+#pragma unroll
+                for (int u = 0; u < Cfg::UPC; ++u) {
+                    if constexpr (DT == DVQ_BF16) {
+                        const bf16x8 w = *reinterpret_cast<const bf16x8*>(sb + (cc * Cfg::UPC + u) * 1024);
+#pragma unroll
+                        for (int np = 0; np < NP; ++np)
+                            acc[np] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xb[np][u], w, acc[np], 0, 0, 0);
+                    } else {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(sb + (cc * Cfg::UPC + u) * 1024);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int np = 0; np < NP; ++np)
+                                acc[np] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xf[np][4 * u + q], w[q], acc[np], 0, 0, 0);
+                    }
+                }
+                float m = acc[0][0];
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[np][i]);
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                if (h == 0) atomicMax(&bmax[(st * Cfg::CPS + cc) * 32 + r], f32_key(m));
+            }
+            __syncthreads();  // next stage landed; this buffer is free for the stage after
+        }
+    }
+
+    // ---- epilogue: bias (and ReLU for the STN trunk) after the max -- both are monotone,
+    // so max_n act(h_n + c) == act(max_n h_n + c) exactly.
+    for (int ch = tid; ch < kC3; ch += kPnThreads) {
+        float v = key_f32(bmax[ch]) + c3[ch];
+        if (relu3) v = v > 0.f ? v : 0.f;
+        feat[(int64_t)b * kC3 + ch] = v;
+    }
+}
+
+template <int DT>
+static size_t pn_lds_bytes() {
+    typedef PnCfg<DT> Cfg;
+    return 2 * (size_t)Cfg::CPS * Cfg::UPC * 1024 + (size_t)Cfg::A2_UNITS * 1024 + (kC1 * 4 + kC1 + kC2) * 4 + kC3 * 4;
+}
+
+template <int DT, int C>
+static int pn_launch(const float* x, const float* trans, int B, int N, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
+    auto kern = pointnet_mlp_max_kernel<DT, C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(DVQ_ELAUNCH, "pointnet: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kPnThreads), pn_lds_bytes<DT>(), st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
+                       reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat);
+    return check_launch("pointnet_mlp_max");
+}
+
+}  // namespace dvq
+
+using namespace dvq;
+
+extern "C" size_t dvq_pointnet_w3_bytes(int dtype) {
+    if (dtype == DVQ_BF16) return (size_t)kC3 * kC2 * 2;
+    if (dtype == DVQ_F32) return (size_t)kC3 * kC2 * 4;
+    set_error("pointnet: unknown dtype %d", dtype);
+    return 0;
+}
+
+extern "C" int dvq_pointnet_pack_w3(const float* a3, int dtype, void* w3p, void* stream) {
+    if (!a3 || !w3p) return fail(DVQ_EINVAL, "pointnet_pack_w3: null pointer");
+    if (((uintptr_t)a3 & 15) || ((uintptr_t)w3p & 15)) return fail(DVQ_EINVAL, "pointnet_pack_w3: pointers must be 16-byte aligned");
+    if (dtype == DVQ_BF16) {
+        const int total = kCt * PnCfg<DVQ_BF16>::UPC * 64;
+        hipLaunchKernelGGL((pn_pack_w3_kernel<DVQ_BF16>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), a3,
+                           reinterpret_cast<uint4*>(w3p));
+    } else if (dtype == DVQ_F32) {
+        const int total = kCt * PnCfg<DVQ_F32>::UPC * 64;
+        hipLaunchKernelGGL((pn_pack_w3_kernel<DVQ_F32>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), a3,
+                           reinterpret_cast<uint4*>(w3p));
+    } else {
+        return fail(DVQ_EINVAL, "pointnet_pack_w3: unknown dtype %d", dtype);
+    }
+    return check_launch("pointnet_pack_w3");
+}
+
+extern "C" int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, int C, int N, const DvqPointMlp* w, int relu3,
+                                    int dtype, float* feat_out, void* stream) {
+    if (B < 0 || N < 1) return fail(DVQ_EINVAL, "pointnet: bad shape B=%d N=%d", B, N);
+    if (C != 3 && C != 4) return fail(DVQ_EINVAL, "pointnet: C must be 3 or 4 (got %d)", C);
+    if (B == 0) return DVQ_OK;
+    if (!x || !w || !feat_out) return fail(DVQ_EINVAL, "pointnet: null pointer");
+    if (!w->a1 || !w->c1 || !w->a2 || !w->c2 || !w->w3p || !w->c3) return fail(DVQ_EINVAL, "pointnet: null weight pointer");
+    if (((uintptr_t)w->a2 & 15) || ((uintptr_t)w->w3p & 15)) return fail(DVQ_EINVAL, "pointnet: a2 and w3p must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    if (dtype == DVQ_BF16) {
+        return C == 3 ? pn_launch<DVQ_BF16, 3>(x, trans, B, N, w, relu3, feat_out, st)
+                      : pn_launch<DVQ_BF16, 4>(x, trans, B, N, w, relu3, feat_out, st);
+    } else if (dtype == DVQ_F32) {
+        return C == 3 ? pn_launch<DVQ_F32, 3>(x, trans, B, N, w, relu3, feat_out, st)
+                      : pn_launch<DVQ_F32, 4>(x, trans, B, N, w, relu3, feat_out, st);
+    }
+    return fail(DVQ_EINVAL, "pointnet: unknown dtype %d", dtype);
+}

@@ -1,0 +1,496 @@
+// Fused nearest-codebook search for the vector quantizer (gfx950).
+//
+// Replaces VectorQuantizer.forward(z, istrain=False) of the reference
+// (DVQ-VAE/network/vqvae/quantizer.py:44-54).  For every latent row z_i the kernel
+// evaluates d[i,k] = fl(fl(|z_i|^2 + |E_k|^2) - 2<z_i,E_k>) for all codes k on the
+// matrix cores and keeps a running (min, first index) per latent in registers; the
+// [n,K] distance matrix is never written anywhere.
+//
+// Mapping onto MFMA 32x32: the CODEBOOK tile is the A operand (32 codes = rows) and
+// the LATENT tile is the B operand (32 latents = columns).  In the 32x32 accumulator
+// layout a lane then owns ONE latent (column lane&31) and 16 codes (rows in its 16
+// registers), so the argmin over codes is a lane-local scan with no cross-lane traffic;
+// the two half-waves (rows +0..3 / +4..7 of each group of 8) are merged once at the end.
+//
+// Data layout
+//   z      [n, D] row-major, streamed once from HBM straight into B-fragment registers
+//          (the whole row of a latent lives in the registers of its two lanes).
+//   E      re-laid once per codebook ("packed") into A-fragment order: a 1-KiB unit
+//          holds, for one tile of 32 codes and one k-step group, the 16 bytes each of
+//          the 64 lanes feeds to the MFMA, so staging into LDS is a linear copy and
+//          every ds_read_b128 is conflict-free.
+//   |E|^2  fp32 [Kpad]; padding codes get +inf and can never win.
+#include "common.h"
+
+namespace dvq {
+
+template <int DT> struct VqTraits;
+template <> struct VqTraits<DVQ_BF16> {
+    typedef unsigned short elem;
+    static constexpr int kDimsPerUnit = 16;  // one 32x32x16 k-step per 1-KiB unit
+};
+template <> struct VqTraits<DVQ_F32> {
+    typedef float elem;
+    static constexpr int kDimsPerUnit = 8;   // four 32x32x2 k-steps per 1-KiB unit
+};
+
+// Which dimension of the row a (unit s, lane half h, element j) triple stands for.
+// Any bijection works as long as both operands use the same one; these make every
+// lane's loads of z 16 contiguous bytes.
+__device__ __host__ __forceinline__ int vq_dim_bf16(int s, int h, int j) { return 16 * s + 8 * h + j; }
+__device__ __host__ __forceinline__ int vq_dim_f32(int s, int h, int i, int D) { return h * (D / 2) + 4 * s + i; }
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------ pack kernel
+template <int DT>
+__global__ void vq_pack_kernel(const typename VqTraits<DT>::elem* __restrict__ E, int K, int D, int Kpad,
+                               uint4* __restrict__ packed, float* __restrict__ e2) {
+    const int U = D / VqTraits<DT>::kDimsPerUnit;
+    const int64_t nchunks = (int64_t)(Kpad / 32) * U * 64;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nchunks) {
+        const int l = (int)(t & 63);
+        const int64_t unit = t >> 6;
+        const int s = (int)(unit % U);
+        const int ct = (int)(unit / U);
+        const int code = ct * 32 + (l & 31);
+        const int h = l >> 5;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (code < K) {
+            if (DT == DVQ_BF16) {
+                v = *reinterpret_cast<const uint4*>(E + (int64_t)code * D + vq_dim_bf16(s, h, 0));
+            } else {
+                v = *reinterpret_cast<const uint4*>(E + (int64_t)code * D + vq_dim_f32(s, h, 0, D));
+            }
+        }
+        packed[t] = v;
+    }
+    if (t < Kpad) {
+        float acc = __builtin_inff();
+        if (t < K) {
+            acc = 0.f;
+            const typename VqTraits<DT>::elem* row = E + t * D;
+            for (int d = 0; d < D; ++d) {
+                float x;
+                if (DT == DVQ_BF16) x = bf16_bits_to_f32((unsigned short)row[d]); else x = (float)row[d];
+                acc = __builtin_fmaf(x, x, acc);
+            }
+        }
+        e2[t] = acc;
+    }
+}
+
+// ------------------------------------------------------------- epilogue pieces
+struct Best {
+    float d;
+    int k;
+};
+
+// Scan the 16 accumulator registers of one 32x32 tile.  Register i holds code
+// tile_base + (i&3) + 8*(i>>2) + 4*h, increasing with i, so a strict '<' keeps the
+// lowest index among equal distances (torch.argmin semantics, quantizer.py:49).
+__device__ __forceinline__ void scan_tile(const f32x16& acc, const float* e2s /* LDS, this tile */, int h,
+                                          int tile_base, float z2, Best& b) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 e = *reinterpret_cast<const f32x4*>(e2s + 8 * g + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t1 = z2 + e[q];                               // fl(|z|^2 + |E_k|^2)
+            const float d = __builtin_fmaf(-2.0f, acc[4 * g + q], t1);  // fl(t1 - 2*dot): 2*dot is exact
+            const int code = tile_base + 8 * g + 4 * h + q;
+            if (d < b.d) { b.d = d; b.k = code; }
+        }
+    }
+}
+
+__device__ __forceinline__ void merge_halves(Best& b) {
+    const float od = __shfl_xor(b.d, 32, 64);
+    const int ok = __shfl_xor(b.k, 32, 64);
+    if (od < b.d || (od == b.d && ok < b.k)) { b.d = od; b.k = ok; }
+}
+
+// Linear copy of `bytes` (multiple of 16) global -> LDS by the whole block.
+__device__ __forceinline__ void stage_copy(const char* __restrict__ src, char* dst, int bytes, int tid, int nthreads) {
+    for (int off = tid * 16; off < bytes; off += nthreads * 16) {
+        *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(src + off);
+    }
+}
+
+// ------------------------------------------------- fast path: z rows in registers
+// One wave owns NB*32 latents; their rows stay in registers for the whole sweep over
+// the codebook.  The codebook streams through LDS in stages of TS tiles (double
+// buffered when there is more than one stage).
+template <int DT, int D, int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void vq_argmin_reg_kernel(
+    const typename VqTraits<DT>::elem* __restrict__ z, const char* __restrict__ packed,
+    const float* __restrict__ e2, int64_t n, int n_tiles, int TS, int64_t* __restrict__ idx_out) {
+    constexpr int U = D / VqTraits<DT>::kDimsPerUnit;       // 1-KiB units per code tile
+    constexpr int TILE_BYTES = U * 1024;
+    constexpr int ZR = (DT == DVQ_BF16) ? U : U * 4;        // fragment registers-groups per latent block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n_stages = (n_tiles + TS - 1) / TS;
+    const int stage_bytes = TS * TILE_BYTES;
+    const int n_buf = n_stages > 1 ? 2 : 1;
+    char* e_lds = smem;                                                  // [n_buf][stage_bytes]
+    float* e2_lds = reinterpret_cast<float*>(smem + n_buf * stage_bytes);  // [n_buf][TS*32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+    constexpr int LAT_PER_BLOCK = WAVES * NB * 32;
+    const int64_t n_groups = (n + LAT_PER_BLOCK - 1) / LAT_PER_BLOCK;
+
+    bool resident = false;  // single-stage codebooks are staged once per block
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t lat0 = grp * LAT_PER_BLOCK + (int64_t)wave * NB * 32;
+        // ---- load this wave's latent rows into B-fragment registers, and |z|^2
+        bf16x8 zb[(DT == DVQ_BF16) ? NB : 1][(DT == DVQ_BF16) ? ZR : 1];
+        f32x4 zf[(DT == DVQ_F32) ? NB : 1][(DT == DVQ_F32) ? U : 1];
+        float z2[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            int64_t row = lat0 + nb * 32 + r;
+            if (row >= n) row = n - 1;  // clamp: the result of such a lane is never stored
+            float part = 0.f;
+            if constexpr (DT == DVQ_BF16) {
+                const unsigned short* zr = reinterpret_cast<const unsigned short*>(z) + row * D;
+#pragma unroll
+                for (int s = 0; s < U; ++s) {
+                    const u16x8 raw = *reinterpret_cast<const u16x8*>(zr + vq_dim_bf16(s, h, 0));
+                    zb[nb][s] = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = bf16_bits_to_f32(raw[j]);
+                        part = __builtin_fmaf(x, x, part);
+                    }
+                }
+            } else {
+                const float* zr = reinterpret_cast<const float*>(z) + row * D;
+#pragma unroll
+                for (int s = 0; s < U; ++s) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(zr + vq_dim_f32(s, h, 0, D));
+                    zf[nb][s] = v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) part = __builtin_fmaf(v[i], v[i], part);
+                }
+            }
+            z2[nb] = part + __shfl_xor(part, 32, 64);
+        }
+        Best best[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { best[nb].d = __builtin_inff(); best[nb].k = 0; }
+
+        // ---- sweep the codebook
+        if (!resident) {
+            const int tiles0 = n_tiles < TS ? n_tiles : TS;
+            stage_copy(packed, e_lds, tiles0 * TILE_BYTES, tid, WAVES * 64);
+            stage_copy(reinterpret_cast<const char*>(e2), reinterpret_cast<char*>(e2_lds), tiles0 * 32 * 4, tid, WAVES * 64);
+            __syncthreads();
+            resident = (n_stages == 1);
+        }
+        for (int st = 0; st < n_stages; ++st) {
+            const int buf = st & (n_buf - 1);
+            const int t_first = st * TS;
+            const int t_count = (n_tiles - t_first) < TS ? (n_tiles - t_first) : TS;
+            if (st + 1 < n_stages) {  // prefetch the next stage into the other buffer
+                const int nf = (st + 1) * TS;
+                const int nc = (n_tiles - nf) < TS ? (n_tiles - nf) : TS;
+                stage_copy(packed + (int64_t)nf * TILE_BYTES, e_lds + (buf ^ 1) * stage_bytes, nc * TILE_BYTES, tid, WAVES * 64);
+                stage_copy(reinterpret_cast<const char*>(e2 + nf * 32), reinterpret_cast<char*>(e2_lds + (buf ^ 1) * TS * 32),
+                           nc * 32 * 4, tid, WAVES * 64);
+            }
+            const char* eb = e_lds + buf * stage_bytes;
+            const float* e2b = e2_lds + buf * TS * 32;
+            for (int t = 0; t < t_count; ++t) {
+                f32x16 acc[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+                const char* tb = eb + t * TILE_BYTES + lane * 16;
+#pragma unroll
+                for (int s = 0; s < U; ++s) {
+                    if constexpr (DT == DVQ_BF16) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(tb + s * 1024);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[nb][s], acc[nb], 0, 0, 0);
+                    } else {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(tb + s * 1024);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], zf[nb][s][i], acc[nb], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    scan_tile(acc[nb], e2b + t * 32, h, (t_first + t) * 32, z2[nb], best[nb]);
+            }
+            if (n_stages > 1) __syncthreads();  // next buffer landed; this one may be overwritten
+        }
+        // a multi-stage sweep leaves the LAST stage in a buffer; the next group restages from 0
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            merge_halves(best[nb]);
+            const int64_t row = lat0 + nb * 32 + r;
+            if (h == 0 && row < n) idx_out[row] = (int64_t)best[nb].k;
+        }
+    }
+}
+
+// --------------------------------------------- generic path: any D % 16 == 0
+// One wave owns 32 latents; z fragments are re-read (L1/L2) for every code tile and the
+// codebook tile is staged through LDS in chunks of CH dims.  Slower; used for the shapes
+// the register path does not cover (e.g. the 1024-wide object codebook).
+template <int DT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void vq_argmin_generic_kernel(
+    const typename VqTraits<DT>::elem* __restrict__ z, const char* __restrict__ packed,
+    const float* __restrict__ e2, int64_t n, int D, int n_tiles, int64_t* __restrict__ idx_out) {
+    constexpr int DPU = VqTraits<DT>::kDimsPerUnit;
+    constexpr int CHU = 32;  // units (KiB) staged per chunk
+    __shared__ __attribute__((aligned(16))) char e_lds[CHU * 1024];
+    const int U = D / DPU;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+    const int64_t n_groups = (n + WAVES * 32 - 1) / (WAVES * 32);
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        int64_t row = grp * (WAVES * 32) + wave * 32 + r;
+        const bool live = row < n;
+        if (!live) row = n - 1;
+        const typename VqTraits<DT>::elem* zr = z + row * D;
+        float part = 0.f;
+        for (int d = h * (D / 2); d < (h + 1) * (D / 2); ++d) {
+            float x;
+            if (DT == DVQ_BF16) x = bf16_bits_to_f32((unsigned short)zr[d]); else x = (float)zr[d];
+            part = __builtin_fmaf(x, x, part);
+        }
+        const float z2 = part + __shfl_xor(part, 32, 64);
+        Best best; best.d = __builtin_inff(); best.k = 0;
+        for (int t = 0; t < n_tiles; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int u0 = 0; u0 < U; u0 += CHU) {
+                const int nu = (U - u0) < CHU ? (U - u0) : CHU;
+                __syncthreads();
+                stage_copy(packed + ((int64_t)t * U + u0) * 1024, e_lds, nu * 1024, tid, WAVES * 64);
+                __syncthreads();
+                for (int s = 0; s < nu; ++s) {
+                    if constexpr (DT == DVQ_BF16) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(e_lds + s * 1024 + lane * 16);
+                        const u16x8 raw = *reinterpret_cast<const u16x8*>(
+                            reinterpret_cast<const unsigned short*>(zr) + vq_dim_bf16(u0 + s, h, 0));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, raw), acc, 0, 0, 0);
+                    } else {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(e_lds + s * 1024 + lane * 16);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(
+                            reinterpret_cast<const float*>(zr) + vq_dim_f32(u0 + s, h, 0, D));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+                    }
+                }
+            }
+            // |E|^2 of this tile straight from global (L1-resident, 128 bytes)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 e = *reinterpret_cast<const f32x4*>(e2 + t * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t1 = z2 + e[q];
+                    const float d = __builtin_fmaf(-2.0f, acc[4 * g + q], t1);
+                    const int code = t * 32 + 8 * g + 4 * h + q;
+                    if (d < best.d) { best.d = d; best.k = code; }
+                }
+            }
+        }
+        merge_halves(best);
+        if (h == 0 && live) idx_out[grp * (WAVES * 32) + wave * 32 + r] = (int64_t)best.k;
+    }
+}
+
+// ------------------------------------------------------------------- row gather
+// out[i, :] = E[idx[i], :] -- z_q of quantizer.py:50-53 and get_emb of :68-75 (the
+// reference multiplies a one-hot matrix by E, which selects the row exactly).
+template <typename T>
+__global__ void vq_gather_kernel(const int64_t* __restrict__ idx, const T* __restrict__ E, int64_t n, int K, int D,
+                                 T* __restrict__ out, int64_t ld_out) {
+    const int vec = 16 / sizeof(T);
+    const int chunks = D / vec;
+    const int64_t total = n * chunks;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / chunks;
+        const int c = (int)(t % chunks);
+        int64_t k = idx[i];
+        if (k < 0) k = 0;
+        if (k >= K) k = K - 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(E + k * D + c * vec);
+        *reinterpret_cast<uint4*>(out + i * ld_out + c * vec) = v;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct VqPlan {
+    int Kpad, n_tiles, U, tile_bytes;
+    size_t packed_bytes, e2_off, total;
+};
+
+static bool vq_plan(int K, int D, int dtype, VqPlan* p) {
+    if (K < 1 || K > 65536 || D < 16 || D > 4096 || (D % 16) != 0) return false;
+    if (dtype != DVQ_F32 && dtype != DVQ_BF16) return false;
+    p->Kpad = round_up(K, 32);
+    p->n_tiles = p->Kpad / 32;
+    p->U = D / (dtype == DVQ_BF16 ? 16 : 8);
+    p->tile_bytes = p->U * 1024;
+    p->packed_bytes = (size_t)p->n_tiles * p->tile_bytes;
+    p->e2_off = (p->packed_bytes + 255) / 256 * 256;
+    p->total = p->e2_off + (size_t)p->Kpad * 4;
+    p->total = (p->total + 255) / 256 * 256;
+    return true;
+}
+
+template <int DT, int D, int NB, int WAVES>
+static int launch_reg(const void* z, const char* ws, const VqPlan& p, int64_t n, int64_t* idx_out, hipStream_t st) {
+    constexpr int U = D / VqTraits<DT>::kDimsPerUnit;
+    constexpr int TILE_BYTES = U * 1024;
+    int TS = 65536 / TILE_BYTES;  // 64 KiB of codebook per stage
+    if (TS < 1) TS = 1;
+    if (TS > p.n_tiles) TS = p.n_tiles;
+    const int n_stages = (p.n_tiles + TS - 1) / TS;
+    const int n_buf = n_stages > 1 ? 2 : 1;
+    const size_t lds = (size_t)n_buf * TS * TILE_BYTES + (size_t)n_buf * TS * 32 * 4;
+    auto kern = vq_argmin_reg_kernel<DT, D, NB, WAVES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(DVQ_ELAUNCH, "vq_argmin: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int64_t groups = (n + WAVES * NB * 32 - 1) / (WAVES * NB * 32);
+    const int64_t max_blocks = (lds > 80 * 1024) ? kNumCU : 2 * kNumCU;
+    const int grid = (int)(groups < max_blocks ? groups : max_blocks);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st,
+                       reinterpret_cast<const typename VqTraits<DT>::elem*>(z), ws, reinterpret_cast<const float*>(ws + p.e2_off),
+                       n, p.n_tiles, TS, idx_out);
+    return check_launch("vq_argmin");
+}
+
+template <int DT>
+static int launch_search(const void* z, const char* ws, const VqPlan& p, int64_t n, int D, int64_t* idx_out, hipStream_t st) {
+    if (n == 0) return DVQ_OK;
+    if (DT == DVQ_BF16) {
+        if (D == 256) return launch_reg<DVQ_BF16, 256, 2, 8>(z, ws, p, n, idx_out, st);
+        if (D == 128) return launch_reg<DVQ_BF16, 128, 2, 8>(z, ws, p, n, idx_out, st);
+        if (D == 64) return launch_reg<DVQ_BF16, 64, 2, 8>(z, ws, p, n, idx_out, st);
+    } else {
+        if (D == 256) return launch_reg<DVQ_F32, 256, 1, 8>(z, ws, p, n, idx_out, st);
+        if (D == 128) return launch_reg<DVQ_F32, 128, 2, 8>(z, ws, p, n, idx_out, st);
+        if (D == 64) return launch_reg<DVQ_F32, 64, 2, 8>(z, ws, p, n, idx_out, st);
+    }
+    constexpr int WAVES = 4;
+    const int64_t groups = (n + WAVES * 32 - 1) / (WAVES * 32);
+    const int grid = (int)(groups < 8 * kNumCU ? groups : 8 * kNumCU);
+    hipLaunchKernelGGL((vq_argmin_generic_kernel<DT, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st,
+                       reinterpret_cast<const typename VqTraits<DT>::elem*>(z), ws, reinterpret_cast<const float*>(ws + p.e2_off),
+                       n, D, p.n_tiles, idx_out);
+    return check_launch("vq_argmin(generic)");
+}
+
+static int vq_check(const void* z, const void* E, int64_t n, int K, int D, int dtype, const int64_t* idx_out,
+                    const void* ws, VqPlan* p) {
+    if (!vq_plan(K, D, dtype, p))
+        return fail(DVQ_EINVAL, "vq: unsupported shape K=%d D=%d dtype=%d (need 1<=K<=65536, 16<=D<=4096, D%%16==0)", K, D, dtype);
+    if (n < 0) return fail(DVQ_EINVAL, "vq: negative n");
+    if (!E || !ws || (n > 0 && (!z || !idx_out))) return fail(DVQ_EINVAL, "vq: null pointer");
+    if (((uintptr_t)ws & 255) != 0) return fail(DVQ_EINVAL, "vq: workspace must be 256-byte aligned");
+    if (((uintptr_t)E & 15) != 0 || ((uintptr_t)z & 15) != 0) return fail(DVQ_EINVAL, "vq: z and E must be 16-byte aligned");
+    return DVQ_OK;
+}
+
+static int vq_prepare_impl(const void* E, int K, int D, int dtype, void* ws, const VqPlan& p, hipStream_t st) {
+    const int64_t nchunks = (int64_t)p.n_tiles * p.U * 64;
+    const int64_t threads = nchunks > p.Kpad ? nchunks : p.Kpad;
+    const int grid = (int)((threads + 255) / 256);
+    char* w = reinterpret_cast<char*>(ws);
+    if (dtype == DVQ_BF16)
+        hipLaunchKernelGGL((vq_pack_kernel<DVQ_BF16>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(E), K, D,
+                           p.Kpad, reinterpret_cast<uint4*>(w), reinterpret_cast<float*>(w + p.e2_off));
+    else
+        hipLaunchKernelGGL((vq_pack_kernel<DVQ_F32>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const float*>(E), K, D, p.Kpad,
+                           reinterpret_cast<uint4*>(w), reinterpret_cast<float*>(w + p.e2_off));
+    return check_launch("vq_prepare");
+}
+
+static int vq_gather_impl(const int64_t* idx, const void* E, int64_t n, int K, int D, int dtype, void* out, int64_t ld,
+                          hipStream_t st) {
+    if (n == 0) return DVQ_OK;
+    const int vec = dtype == DVQ_BF16 ? 8 : 4;
+    const int64_t total = n * (D / vec);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == DVQ_BF16)
+        hipLaunchKernelGGL((vq_gather_kernel<unsigned short>), dim3(grid), dim3(256), 0, st, idx, reinterpret_cast<const unsigned short*>(E),
+                           n, K, D, reinterpret_cast<unsigned short*>(out), ld);
+    else
+        hipLaunchKernelGGL((vq_gather_kernel<float>), dim3(grid), dim3(256), 0, st, idx, reinterpret_cast<const float*>(E), n, K, D,
+                           reinterpret_cast<float*>(out), ld);
+    return check_launch("vq_gather");
+}
+
+}  // namespace dvq
+
+using namespace dvq;
+
+extern "C" size_t dvq_vq_workspace_bytes(int K, int D, int dtype) {
+    VqPlan p;
+    if (!vq_plan(K, D, dtype, &p)) {
+        set_error("vq: unsupported shape K=%d D=%d dtype=%d", K, D, dtype);
+        return 0;
+    }
+    return p.total;
+}
+
+extern "C" int dvq_vq_prepare(const void* E, int K, int D, int dtype, void* workspace, void* stream) {
+    VqPlan p;
+    int rc = vq_check(nullptr, E, 0, K, D, dtype, nullptr, workspace, &p);
+    if (rc) return rc;
+    return vq_prepare_impl(E, K, D, dtype, workspace, p, as_stream(stream));
+}
+
+extern "C" int dvq_vq_argmin_prepared(const void* z, const void* E, int64_t n, int K, int D, int dtype, int64_t* idx_out,
+                                      void* zq_out, const void* workspace, void* stream) {
+    VqPlan p;
+    int rc = vq_check(z, E, n, K, D, dtype, idx_out, workspace, &p);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    const char* ws = reinterpret_cast<const char*>(workspace);
+    rc = (dtype == DVQ_BF16) ? launch_search<DVQ_BF16>(z, ws, p, n, D, idx_out, st) : launch_search<DVQ_F32>(z, ws, p, n, D, idx_out, st);
+    if (rc) return rc;
+    if (zq_out) return vq_gather_impl(idx_out, E, n, K, D, dtype, zq_out, D, st);
+    return DVQ_OK;
+}
+
+extern "C" int dvq_vq_argmin(const void* z, const void* E, int64_t n, int K, int D, int dtype, int64_t* idx_out, void* zq_out,
+                             void* workspace, void* stream) {
+    VqPlan p;
+    int rc = vq_check(z, E, n, K, D, dtype, idx_out, workspace, &p);
+    if (rc) return rc;
+    rc = vq_prepare_impl(E, K, D, dtype, workspace, p, as_stream(stream));
+    if (rc) return rc;
+    return dvq_vq_argmin_prepared(z, E, n, K, D, dtype, idx_out, zq_out, workspace, stream);
+}
+
+extern "C" int dvq_vq_gather(const int64_t* idx, const float* E, int64_t n, int K, int D, float* out, int64_t ld_out, void* stream) {
+    if (n < 0 || K < 1 || D < 4 || (D % 4) != 0 || ld_out < D || (ld_out % 4) != 0)
+        return fail(DVQ_EINVAL, "vq_gather: bad shape n=%lld K=%d D=%d ld=%lld", (long long)n, K, D, (long long)ld_out);
+    if (n > 0 && (!idx || !E || !out)) return fail(DVQ_EINVAL, "vq_gather: null pointer");
+    if (((uintptr_t)E & 15) || ((uintptr_t)out & 15)) return fail(DVQ_EINVAL, "vq_gather: E and out must be 16-byte aligned");
+    return vq_gather_impl(idx, E, n, K, D, DVQ_F32, out, ld_out, as_stream(stream));
+}

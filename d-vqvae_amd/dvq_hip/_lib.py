@@ -1,0 +1,71 @@
+"""ctypes binding of libdvq_hip.so (declared in include/dvq_hip.h).
+
+There is no CPU or eager-PyTorch fallback: if the library is missing the import of
+any module that needs a kernel raises, and every call with a non-zero status raises
+RuntimeError carrying dvq_last_error().
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdvq_hip.so")
+
+DVQ_F32 = 0
+DVQ_BF16 = 1
+
+
+class DvqPointMlp(ctypes.Structure):
+    _fields_ = [("a1", c_void_p), ("c1", c_void_p), ("a2", c_void_p), ("c2", c_void_p),
+                ("w3p", c_void_p), ("c3", c_void_p)]
+
+
+class DvqManoConsts(ctypes.Structure):
+    _fields_ = [("n_verts", c_int), ("n_comps", c_int), ("v_shaped", c_void_p), ("joints", c_void_p),
+                ("posedirs", c_void_p), ("lbs_weights", c_void_p), ("components", c_void_p),
+                ("pose_mean", c_void_p), ("parents", c_void_p)]
+
+
+# name -> (restype, argtypes); mirrors include/dvq_hip.h one to one
+SIGNATURES = {
+    "dvq_version": (c_int, []),
+    "dvq_last_error": (c_char_p, []),
+    "dvq_vq_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dvq_vq_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dvq_vq_argmin": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dvq_vq_argmin_prepared": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dvq_vq_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "dvq_pointnet_w3_bytes": (c_size_t, [c_int]),
+    "dvq_pointnet_pack_w3": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "dvq_pointnet_mlp_max": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DvqPointMlp), c_int, c_int, c_void_p, c_void_p]),
+    "dvq_fold_bn": (c_int, [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dvq_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libdvq_hip.so not found at {LIB_PATH}: build it with `make -C d-vqvae_amd/csrc` "
+                "(there is no fallback path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().dvq_last_error()
+        raise RuntimeError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")

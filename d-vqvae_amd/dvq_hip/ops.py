@@ -1,0 +1,178 @@
+"""Tensor-level wrappers over the C ABI: device pointers + torch's current HIP stream in,
+status checked, outputs returned as fresh torch tensors on the input's device.
+
+torch is used here for memory and streams only.  Every function requires its tensors
+to live on a HIP device and raises otherwise -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DVQ_BF16, DVQ_F32, DvqManoConsts, DvqPointMlp
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("dvq_hip kernels need tensors on a HIP device (got a CPU tensor); "
+                               "there is no CPU fallback")
+        if not t.is_contiguous():
+            raise RuntimeError("dvq_hip kernels need contiguous tensors")
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return DVQ_F32
+    if t.dtype == torch.bfloat16:
+        return DVQ_BF16
+    raise RuntimeError(f"unsupported dtype {t.dtype}: float32 or bfloat16 expected")
+
+
+# --------------------------------------------------------------------------- VQ
+def vq_workspace(K: int, D: int, dtype: torch.dtype, device) -> torch.Tensor:
+    code = DVQ_F32 if dtype == torch.float32 else DVQ_BF16
+    nbytes = _lib.load().dvq_vq_workspace_bytes(K, D, code)
+    if nbytes == 0:
+        _lib.check(-1, "dvq_vq_workspace_bytes")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def vq_prepare(E: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Re-lay the codebook E [K,D] for the search kernel; returns the filled workspace."""
+    _need_gpu(E)
+    K, D = E.shape
+    ws = workspace if workspace is not None else vq_workspace(K, D, E.dtype, E.device)
+    with torch.cuda.device(E.device):
+        _lib.check(_lib.load().dvq_vq_prepare(_p(E), K, D, _dtype_code(E), _p(ws), _stream(E)), "dvq_vq_prepare")
+    return ws
+
+
+def vq_argmin(z: torch.Tensor, E: torch.Tensor, want_zq: bool = True,
+              prepared: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """idx int64 [n], z_q [n,D] (or None) for latents z [n,D] against codebook E [K,D]."""
+    _need_gpu(z, E, prepared)
+    if z.dtype != E.dtype:
+        raise RuntimeError("vq_argmin: z and E must have the same dtype")
+    n, D = z.shape
+    K = E.shape[0]
+    if E.shape[1] != D:
+        raise RuntimeError(f"vq_argmin: z has {D} dims, codebook {E.shape[1]}")
+    idx = torch.empty(n, dtype=torch.int64, device=z.device)
+    zq = torch.empty_like(z) if want_zq else None
+    lib = _lib.load()
+    with torch.cuda.device(z.device):
+        if prepared is None:
+            ws = vq_workspace(K, D, E.dtype, E.device)
+            rc = lib.dvq_vq_argmin(_p(z), _p(E), n, K, D, _dtype_code(z), _p(idx), _p(zq), _p(ws), _stream(z))
+        else:
+            rc = lib.dvq_vq_argmin_prepared(_p(z), _p(E), n, K, D, _dtype_code(z), _p(idx), _p(zq), _p(prepared), _stream(z))
+    _lib.check(rc, "dvq_vq_argmin")
+    return idx, zq
+
+
+def vq_gather(idx: torch.Tensor, E: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = E[idx[b]] (fp32).  `out` may be a column slice of a wider row-major buffer."""
+    _need_gpu(idx, E)
+    if idx.dtype != torch.int64 or E.dtype != torch.float32:
+        raise RuntimeError("vq_gather: idx must be int64 and E float32")
+    n = idx.numel()
+    K, D = E.shape
+    if out is None:
+        out = torch.empty(n, D, dtype=torch.float32, device=E.device)
+    if not out.is_cuda or out.stride(1) != 1 or out.shape != (n, D):
+        raise RuntimeError("vq_gather: bad output view")
+    with torch.cuda.device(E.device):
+        rc = _lib.load().dvq_vq_gather(_p(idx), _p(E), n, K, D, _p(out), out.stride(0) if n > 1 else max(D, out.stride(0)), _stream(E))
+    _lib.check(rc, "dvq_vq_gather")
+    return out
+
+
+# --------------------------------------------------------------------- PointNet
+def fold_bn(W, b, gamma, beta, mean, var, eps: float = 1e-5):
+    """(A, c) with the eval-mode BatchNorm folded into the affine layer (W [out,in])."""
+    _need_gpu(W, b, gamma, beta, mean, var)
+    out_f, in_f = W.shape
+    A = torch.empty_like(W)
+    c = torch.empty_like(b)
+    with torch.cuda.device(W.device):
+        rc = _lib.load().dvq_fold_bn(_p(W), _p(b), _p(gamma), _p(beta), _p(mean), _p(var), eps, out_f, in_f,
+                                     _p(A), _p(c), _stream(W))
+    _lib.check(rc, "dvq_fold_bn")
+    return A, c
+
+
+def pointnet_pack_w3(a3: torch.Tensor, dtype_code: int) -> torch.Tensor:
+    _need_gpu(a3)
+    nbytes = _lib.load().dvq_pointnet_w3_bytes(dtype_code)
+    out = torch.empty(nbytes, dtype=torch.uint8, device=a3.device)
+    with torch.cuda.device(a3.device):
+        rc = _lib.load().dvq_pointnet_pack_w3(_p(a3), dtype_code, _p(out), _stream(a3))
+    _lib.check(rc, "dvq_pointnet_pack_w3")
+    return out
+
+
+def pointnet_mlp_max(x: torch.Tensor, trans: Optional[torch.Tensor], w: dict, relu3: bool, dtype_code: int) -> torch.Tensor:
+    """Shared per-point MLP C->64->128->1024 + max over points.  x [B,C,N] fp32 ->
+    [B,1024] fp32.  `w` holds the folded tensors a1,c1,a2,c2,c3 and the packed w3p."""
+    _need_gpu(x, trans, w["a1"], w["c1"], w["a2"], w["c2"], w["w3p"], w["c3"])
+    B, C, N = x.shape
+    feat = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
+    s = DvqPointMlp(w["a1"].data_ptr(), w["c1"].data_ptr(), w["a2"].data_ptr(), w["c2"].data_ptr(),
+                    w["w3p"].data_ptr(), w["c3"].data_ptr())
+    with torch.cuda.device(x.device):
+        rc = _lib.load().dvq_pointnet_mlp_max(_p(x), _p(trans), B, C, N, ctypes.byref(s), int(relu3), dtype_code,
+                                              _p(feat), _stream(x))
+    _lib.check(rc, "dvq_pointnet_mlp_max")
+    return feat
+
+
+# ----------------------------------------------------------------------- linear
+def linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
+           add_identity3: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x W^T + b) in fp32.  x [M,K] and `out` [M,N] may be column slices of wider
+    row-major buffers (unit inner stride)."""
+    _need_gpu(W, b)
+    if not x.is_cuda or x.stride(-1) != 1 or x.dim() != 2:
+        raise RuntimeError("linear: x must be a 2-D HIP tensor with unit inner stride")
+    M, K = x.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise RuntimeError(f"linear: x has {K} features, weight expects {W.shape[1]}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    ldx = x.stride(0) if M > 1 else max(K, x.stride(0))
+    ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
+    with torch.cuda.device(x.device):
+        rc = _lib.load().dvq_linear(_p(x), ldx, _p(W), _p(b), M, K, N, int(relu), int(add_identity3), _p(out), ldy, _stream(x))
+    _lib.check(rc, "dvq_linear")
+    return out
+
+
+# ------------------------------------------------------------------------- MANO
+def mano_lbs(global_orient, hand_pose, transl, consts: DvqManoConsts, n_verts: int,
+             want_joints: bool = True, want_full_pose: bool = False):
+    _need_gpu(global_orient, hand_pose, transl)
+    B = hand_pose.shape[0]
+    dev = hand_pose.device
+    verts = torch.empty(B, n_verts, 3, dtype=torch.float32, device=dev)
+    joints = torch.empty(B, 16, 3, dtype=torch.float32, device=dev) if want_joints else None
+    full = torch.empty(B, 48, dtype=torch.float32, device=dev) if want_full_pose else None
+    with torch.cuda.device(dev):
+        rc = _lib.load().dvq_mano_lbs(_p(global_orient), _p(hand_pose), _p(transl), B, ctypes.byref(consts),
+                                      _p(verts), _p(joints), _p(full), _stream(hand_pose))
+    _lib.check(rc, "dvq_mano_lbs")
+    return verts, joints, full

@@ -1,0 +1,99 @@
+"""DVQVAE and its MLP heads on the HIP kernels.
+
+Mirrors DVQ-VAE/network/DVQVAE.py: DVQVAE(obj_inchannel=4), Encoder(layer_sizes, latent_size),
+Decoder(layer_sizes, latent_size) with the reference's submodule names (emb_{i}, fing_{i},
+obj_encoder_type/pos, vqvae0..6, decoder, recon_encoder, pos_decoder, MLP.L{i},
+linear_means, linear_log_var).  Only the eval branch of DVQVAE.forward is implemented:
+(obj_pc [B,4,N], hand_xyz [B,3,778]) -> (emb_idx int64 [7B,1], obj_emb [B,1024]).
+
+The reference reads an undefined name for the first hand part (DVQVAE.py:93); the vertex
+set used here is the documented reconstruction in dvq_hip.hand_parts.
+"""
+import torch
+import torch.nn as nn
+
+from dvq_hip import ops
+from dvq_hip.hand_parts import HAND_PARTS
+from network.pointnet_encoder import PointNetEncoder
+from network.VQVAE import VQVAE
+
+
+def _linear(layer, x, relu=False, out=None):
+    return ops.linear(x, layer.weight.detach(), layer.bias.detach(), relu=relu, out=out)
+
+
+class Encoder(nn.Module):
+    def __init__(self, layer_sizes, latent_size):
+        super().__init__()
+        self.MLP = nn.Sequential()
+        for i, (in_size, out_size) in enumerate(zip(layer_sizes[:-1], layer_sizes[1:])):
+            self.MLP.add_module(name="L{:d}".format(i), module=nn.Linear(in_size, out_size))
+            self.MLP.add_module(name="A{:d}".format(i), module=nn.ReLU())
+        self.linear_means = nn.Linear(layer_sizes[-1], latent_size)
+        self.linear_log_var = nn.Linear(layer_sizes[-1], latent_size)  # in the checkpoint, never used
+
+    def forward(self, x, out=None):
+        x = x.detach()
+        for m in self.MLP:
+            if isinstance(m, nn.Linear):
+                x = _linear(m, x, relu=True)
+        return _linear(self.linear_means, x, out=out)
+
+
+class Decoder(nn.Module):
+    def __init__(self, layer_sizes, latent_size):
+        super().__init__()
+        self.MLP = nn.Sequential()
+        for i, (in_size, out_size) in enumerate(zip([latent_size] + layer_sizes[:-1], layer_sizes)):
+            self.MLP.add_module(name="L{:d}".format(i), module=nn.Linear(in_size, out_size))
+            if i + 1 < len(layer_sizes):
+                self.MLP.add_module(name="A{:d}".format(i), module=nn.ReLU())
+
+    def forward(self, z):
+        x = z.detach()
+        layers = [m for m in self.MLP if isinstance(m, nn.Linear)]
+        for i, m in enumerate(layers):
+            x = _linear(m, x, relu=(i + 1 < len(layers)))
+        return x
+
+
+class DVQVAE(nn.Module):
+    def __init__(self, obj_inchannel=4):
+        super().__init__()
+        self.obj_inchannel = obj_inchannel
+        self.handembnns = [Encoder([1024, 512], 256) for _ in range(6)]
+        for i, emb in enumerate(self.handembnns):
+            self.add_module('emb_{}'.format(i), emb)
+        self.obj_encoder_type = PointNetEncoder(global_feat=True, feature_transform=False, channel=obj_inchannel)
+        self.obj_encoder_pos = PointNetEncoder(global_feat=True, feature_transform=False, channel=obj_inchannel)
+        self.hand_encoders = [PointNetEncoder(global_feat=True, feature_transform=False, channel=3) for _ in range(6)]
+        for i, enc in enumerate(self.hand_encoders):
+            self.add_module('fing_{}'.format(i), enc)
+        for k in range(6):
+            setattr(self, f"vqvae{k}", VQVAE(h_dim=128, res_h_dim=32, n_res_layers=2, n_embeddings=128,
+                                             embedding_dim=256, beta=0.25, a=1))
+        self.vqvae6 = VQVAE(h_dim=128, res_h_dim=32, n_res_layers=2, n_embeddings=128, embedding_dim=1024, beta=2, a=0)
+        self.decoder = Decoder(layer_sizes=[1024, 256, 55], latent_size=2560)
+        self.rh_mano = None
+        self.recon_encoder = PointNetEncoder(global_feat=True, feature_transform=False, channel=3)
+        self.pos_decoder = Decoder(layer_sizes=[1024, 128, 6], latent_size=2048)
+
+    def set_rh_mano(self, Rh_mano):
+        self.rh_mano = Rh_mano
+        Rh_mano.eval()
+
+    def forward(self, obj_pc, hand_xyz):
+        if self.training:
+            raise RuntimeError("DVQVAE: only the inference branch is implemented; call model.eval()")
+        hand_xyz = hand_xyz.detach()
+        hand_xyz = hand_xyz - hand_xyz.mean(dim=2, keepdim=True)      # centre the hand (DVQVAE.py:49-51)
+        obj_feat_type, _, _ = self.obj_encoder_type(obj_pc)
+        idxs = []
+        for k in range(6):
+            part = hand_xyz[:, :, HAND_PARTS[k]].contiguous()
+            feat, _, _ = self.hand_encoders[k](part)
+            latent = self.handembnns[k](feat)
+            idx_k, _ = getattr(self, f"vqvae{k}").inference(latent)
+            idxs.append(idx_k)
+        idx6, obj_emb = self.vqvae6.inference(obj_feat_type)
+        return torch.cat([idx6] + idxs, 0), obj_emb

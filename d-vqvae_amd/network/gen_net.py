@@ -1,0 +1,85 @@
+"""GenNet: object cloud -> MANO parameters, on the HIP kernels.
+
+Mirrors DVQ-VAE/network/gen_net.py:13-125: same submodule names (333 state_dict keys,
++14 `rh_mano.*` after set_rh_mano), gen(obj [B,4,N]) -> (recon [B,55], recon_pos [B,6]).
+The reference's gen() is only valid at batch 1; here any B works and row b equals the
+reference applied to obj[b:b+1].  Tensors stay on the input's device.
+
+gen(obj, x_tilde=None, generator=None): `x_tilde` (int64 [B,3,3]) bypasses the
+autoregressive prior with given part indices (teacher forcing); otherwise the prior is
+sampled, optionally with a torch.Generator for reproducibility.
+"""
+import torch
+import torch.nn as nn
+
+from dvq_hip import ops
+from network.DVQVAE import Decoder, Encoder  # noqa: F401  (re-exported like the reference)
+from network.pixelcnn.models import GatedPixelCNN
+from network.pointnet_encoder import PointNetEncoder
+from network.VQVAE import VQVAE
+
+# grid cells of the prior sample that hold part indices 0..5 (gen_net.py:95-100)
+PART_CELLS = ((0, 1), (0, 2), (1, 1), (1, 2), (2, 1), (2, 2))
+
+
+class GenNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.obj_encoder_type = PointNetEncoder(global_feat=True, feature_transform=False, channel=4)
+        self.obj_encoder_pos = PointNetEncoder(global_feat=True, feature_transform=False, channel=4)
+        for k in range(6):
+            setattr(self, f"vqvae{k}", VQVAE(h_dim=128, res_h_dim=32, n_res_layers=2, n_embeddings=128,
+                                             embedding_dim=256, beta=0.25, a=1))
+        self.vqvae6 = VQVAE(h_dim=128, res_h_dim=32, n_res_layers=2, n_embeddings=128, embedding_dim=1024, beta=2, a=0)
+        self.decoder = Decoder(layer_sizes=[1024, 256, 55], latent_size=2560)
+        self.num = 0
+        self.rh_mano = None
+        self.recon_encoder = PointNetEncoder(global_feat=True, feature_transform=False, channel=3)
+        self.pos_decoder = Decoder(layer_sizes=[1024, 128, 6], latent_size=2048)
+        self.GatedPixelCNN = GatedPixelCNN(512, 512, 15)
+
+    def set_rh_mano(self, Rh_mano):
+        Rh_mano.eval()
+        self.rh_mano = Rh_mano
+
+    def _decode(self, part_idx, obj_feat_type, obj_feat_pos):
+        """codebook rows + object feature -> decoder -> MANO -> recon encoder -> pos decoder
+        (gen_net.py:101-123).  part_idx: int64 [B,6]."""
+        B = obj_feat_type.shape[0]
+        z_out = torch.empty(B, 2560, dtype=torch.float32, device=obj_feat_type.device)
+        for k in range(6):
+            cb = getattr(self, f"vqvae{k}").vector_quantization.embedding.weight.detach()
+            ops.vq_gather(part_idx[:, k].contiguous(), cb, out=z_out[:, 256 * k:256 * (k + 1)])
+        z_out[:, 1536:] = obj_feat_type        # the un-quantised object feature (gen_net.py:109)
+        recon = self.decoder(z_out).view(B, 55)
+        zero3 = torch.zeros(B, 3, dtype=torch.float32, device=recon.device)
+        verts = self.rh_mano(betas=recon[:, :10], global_orient=zero3, hand_pose=recon[:, 10:55].contiguous(),
+                             transl=zero3).vertices
+        hand_feat, _, _ = self.recon_encoder(verts.detach().permute(0, 2, 1).contiguous())
+        pos = self.pos_decoder(torch.cat((hand_feat, obj_feat_pos), 1)).view(B, 6)
+        return recon, pos
+
+    def gen(self, obj, x_tilde=None, generator=None):
+        if self.rh_mano is None:
+            raise RuntimeError("GenNet.gen: call set_rh_mano(mano_layer) first")
+        B = obj.size()[0]
+        obj_feat_type, _, _ = self.obj_encoder_type(obj)
+        obj_feat_pos, _, _ = self.obj_encoder_pos(obj)
+        idx6, _obj_emb = self.vqvae6.inference(obj_feat_type)
+        if x_tilde is None:
+            label = idx6[:, 0]
+            x_tilde = self.GatedPixelCNN.generate(None, label, shape=(3, 3), batch_size=B, generator=generator)
+        part_idx = torch.stack([x_tilde[:, r, c] for r, c in PART_CELLS], dim=1).to(torch.int64)
+        self.last_x_tilde = x_tilde
+        self.last_idx6 = idx6
+        return self._decode(part_idx, obj_feat_type, obj_feat_pos)
+
+    def gen_byid(self, idx6):
+        """gen_net.py:41-75: samples the prior for a given object code and decodes an
+        all-zero latent (the reference ignores the sampled indices here)."""
+        B = idx6.reshape(-1).shape[0]
+        label = idx6.reshape(-1).to(torch.int64)
+        self.GatedPixelCNN.generate(None, label, shape=(3, 3), batch_size=B)
+        dev = label.device
+        recon = self.decoder(torch.zeros(B, 2560, device=dev)).view(B, 55)
+        return recon, torch.zeros(B, 6, device=dev)

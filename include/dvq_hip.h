@@ -1,0 +1,144 @@
+/*
+ * dvq_hip.h -- C ABI of libdvq_hip.so: MI355X (gfx950) kernels for the D-VQVAE
+ * grasp-generation inference path.
+ *
+ * The reference (MICLAB-BUPT/D-VQVAE) has no FFI of its own: its boundary is the
+ * Python nn.Module surface.  Each entry point below replaces the body of one
+ * reference forward(); the Python modules under d-vqvae_amd/network and
+ * d-vqvae_amd/mano keep the reference's class names, signatures and state_dict
+ * keys and call these through ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to a contiguous row-major buffer owned by
+ *    the caller; nothing here allocates, frees or synchronises;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *  - every function returns DVQ_OK (0) or a negative DVQ_E* code and never aborts;
+ *    dvq_last_error() then describes the failure (per calling thread);
+ *  - dtype: DVQ_F32 = exact fp32 arithmetic, DVQ_BF16 = bf16 operands with fp32
+ *    accumulation.
+ */
+#ifndef DVQ_HIP_H
+#define DVQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVQ_OK 0
+#define DVQ_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define DVQ_ELAUNCH (-2)  /* the HIP runtime rejected a launch               */
+#define DVQ_ENODEV (-3)   /* no usable gfx950 device                         */
+
+#define DVQ_F32 0
+#define DVQ_BF16 1
+
+#define DVQ_VERSION 100   /* major*10000 + minor*100 + patch */
+
+int dvq_version(void);
+const char* dvq_last_error(void);
+
+/* ---------------------------------------------------------------- VQ argmin
+ * Replaces VectorQuantizer.forward(z, istrain=False)
+ * (reference: DVQ-VAE/network/vqvae/quantizer.py:44-54):
+ *   d[i,k] = fl( fl(|z_i|^2 + |E_k|^2) - 2 * <z_i, E_k> ),  idx[i] = first argmin_k d[i,k]
+ *   z_q[i] = E[idx[i]]
+ * The [n,K] distance matrix stays in registers.  z: [n,D], E: [K,D], both of `dtype`
+ * (float for DVQ_F32, bfloat16 bits for DVQ_BF16).  idx_out: int64 [n].  zq_out
+ * (nullable): [n,D] of `dtype`, an exact copy of the chosen rows.
+ * Limits: D % 16 == 0, 16 <= D <= 4096, 1 <= K <= 65536, n >= 0.
+ *
+ * `workspace` holds the codebook re-laid in MFMA fragment order plus |E_k|^2:
+ * dvq_vq_workspace_bytes(K, D, dtype) bytes, 256-byte aligned.
+ *   dvq_vq_prepare : fills the workspace from E (once per codebook version).
+ *   dvq_vq_argmin  : prepare + search in one call (workspace is scratch).
+ *   dvq_vq_argmin_prepared : search only, on a workspace filled by dvq_vq_prepare
+ *                    with the same (E, K, D, dtype).
+ */
+size_t dvq_vq_workspace_bytes(int K, int D, int dtype);
+int dvq_vq_prepare(const void* E, int K, int D, int dtype, void* workspace, void* stream);
+int dvq_vq_argmin(const void* z, const void* E, int64_t n, int K, int D, int dtype,
+                  int64_t* idx_out, void* zq_out, void* workspace, void* stream);
+int dvq_vq_argmin_prepared(const void* z, const void* E, int64_t n, int K, int D, int dtype,
+                           int64_t* idx_out, void* zq_out, const void* workspace, void* stream);
+
+/* Replaces VectorQuantizer.get_emb (quantizer.py:68-75), batched: out[b] = E[idx[b]].
+ * idx: int64 [n]; E, out: float.  `ld_out` is the row stride of `out` in elements
+ * (>= D) so that rows can be written straight into a wider concatenated buffer. */
+int dvq_vq_gather(const int64_t* idx, const float* E, int64_t n, int K, int D,
+                  float* out, int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------- PointNet encoder
+ * Replaces the per-point shared MLP + global max-pool of STN3d.forward and
+ * PointNetEncoder.forward (reference: DVQ-VAE/network/pointnet_encoder.py:27-33 and
+ * :146-164):  per point  h1 = relu(A1 x + c1) [64],  h2 = relu(A2 h1 + c2) [128],
+ * h3 = A3 h2 + c3 [1024] (optionally relu), then max over the N points.
+ * A*, c* are the Conv1d(k=1) weights with the eval-mode BatchNorm folded in
+ * (dvq_fold_bn).  When `trans` is given the xyz channels of every point are first
+ * multiplied by the cloud's 3x3 matrix (row vector times matrix, :146).
+ *
+ * x: float [B,C,N] (channel-major, as the reference's datasets produce), C = 3 or 4.
+ * trans: float [B,3,3] or NULL.  feat_out: float [B,1024].
+ * w3p: A3 packed by dvq_pointnet_pack_w3 for `dtype`.
+ */
+typedef struct {
+    const float* a1;   /* [64, C]   */
+    const float* c1;   /* [64]      */
+    const float* a2;   /* [128, 64] */
+    const float* c2;   /* [128]     */
+    const void*  w3p;  /* packed [1024,128], see dvq_pointnet_pack_w3 */
+    const float* c3;   /* [1024]    */
+} DvqPointMlp;
+
+size_t dvq_pointnet_w3_bytes(int dtype);
+int dvq_pointnet_pack_w3(const float* a3 /* [1024,128] */, int dtype, void* w3p, void* stream);
+int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, int C, int N,
+                         const DvqPointMlp* w, int relu3, int dtype, float* feat_out, void* stream);
+
+/* Folds an eval-mode BatchNorm1d into the preceding affine layer:
+ *   s = gamma / sqrt(var + eps);  A = s * W (row-wise);  c = s * (b - mean) + beta.
+ * W: [out,in] -> A: [out,in];  b, gamma, beta, mean, var, c: [out]. */
+int dvq_fold_bn(const float* W, const float* b, const float* gamma, const float* beta,
+                const float* mean, const float* var, float eps, int out_f, int in_f,
+                float* A, float* c, void* stream);
+
+/* ----------------------------------------------------------------- linear
+ * y = act(x W^T + b): the nn.Linear(+ReLU) layers of the STN head
+ * (pointnet_encoder.py:35-37) and of Encoder/Decoder (DVQ-VAE/network/DVQVAE.py:161-185).
+ * x: [M, K] with row stride ldx; W: [N, K]; b: [N] or NULL; y: [M, N] with row stride ldy.
+ * add_identity3 != 0 adds the flattened 3x3 identity to a 9-wide output (pointnet_encoder.py:39-43).
+ * fp32 arithmetic. */
+int dvq_linear(const float* x, int64_t ldx, const float* W, const float* b, int M, int K, int N,
+               int relu, int add_identity3, float* y, int64_t ldy, void* stream);
+
+/* ------------------------------------------------------------------- MANO
+ * Replaces MANO.forward + lbs (reference: DVQ-VAE-2/MANO-master/mano/model.py:311-359,
+ * mano/lbs.py:33-265) for use_pca=True, pose2rot=True.  As in the reference the shape
+ * coefficients passed by the caller are ignored (model.py:335 hands lbs the module's own
+ * zero betas), so v_shaped and the rest joints are constants precomputed on the host.
+ *
+ * global_orient: [B,3]; hand_pose: [B,ncomps] PCA coefficients; transl: [B,3] or NULL.
+ * verts_out: [B,V,3]; joints_out: [B,16,3] or NULL; full_pose_out: [B,48] or NULL.
+ */
+typedef struct {
+    int n_verts;              /* V (778)                                  */
+    int n_comps;              /* PCA components in use (<= 45)            */
+    const float* v_shaped;    /* [V,3]  v_template + betas*shapedirs      */
+    const float* joints;      /* [16,3] J_regressor * v_shaped            */
+    const float* posedirs;    /* [135, V*3]                               */
+    const float* lbs_weights; /* [V,16]                                   */
+    const float* components;  /* [n_comps,45]                             */
+    const float* pose_mean;   /* [48]                                     */
+    const int*   parents;     /* [16], parents[0] = -1                    */
+} DvqManoConsts;
+
+int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float* transl, int B,
+                 const DvqManoConsts* m, float* verts_out, float* joints_out, float* full_pose_out,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVQ_HIP_H */

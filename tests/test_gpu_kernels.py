@@ -1,0 +1,150 @@
+"""MANO, linear and PointNet kernels vs the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from dvq_hip import ops, synth
+from dvq_hip.mano_io import Struct
+from oracle import dvq_oracle as O
+from parity import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_mano(batch_size=1):
+    import mano
+    return mano.MANO('', data_struct=Struct(**synth.mano_model_data(0)), use_pca=True, num_pca_comps=45,
+                     batch_size=batch_size, flat_hand_mean=True).to(DEV).eval()
+
+
+def test_mano_vs_reference_golden():
+    g = load_golden("mano")
+    rh = make_mano(8)
+    go, hp, tr = (torch.from_numpy(g[k]).to(DEV) for k in ("global_orient", "hand_pose", "transl"))
+    out = rh(betas=torch.full((8, 10), 5.0, device=DEV), global_orient=go, hand_pose=hp, transl=tr, return_full_pose=True)
+    assert out.vertices.shape == (8, 778, 3) and out.joints.shape == (8, 16, 3)
+    # tolerance of the task: 1e-4 relative on vertices in fp32
+    assert rel_err(out.vertices, g["vertices"]) <= 1e-5
+    assert rel_err(out.joints, g["joints"]) <= 1e-5
+    assert rel_err(out.full_pose, g["full_pose"]) <= 1e-6
+
+
+@pytest.mark.parametrize("B", [1, 3, 8, 9, 67])
+def test_mano_batches_vs_oracle(B):
+    rh = make_mano(1)
+    go, hp, tr = synth.mano_inputs(B, seed=B)
+    sd = synth.mano_state_dict(0, batch_size=1)
+    v_ref, j_ref, _ = O.mano_forward(sd, go, hp, tr)
+    out = rh(global_orient=go.to(DEV), hand_pose=hp.to(DEV), transl=tr.to(DEV))
+    assert rel_err(out.vertices, v_ref) <= 1e-5 and rel_err(out.joints, j_ref) <= 1e-5
+    out2 = rh(global_orient=go.to(DEV), hand_pose=hp.to(DEV), transl=None)   # module's own zero transl
+    v0, _, _ = O.mano_forward(sd, go, hp, torch.zeros(B, 3))
+    assert rel_err(out2.vertices, v0) <= 1e-5
+
+
+def test_mano_full_size_linearity_in_translation():
+    """B = 4096: vertices(transl=t) - vertices(transl=0) must be t for every vertex, and a
+    slice of the batch must equal the same rows computed alone."""
+    B = 4096
+    rh = make_mano(1)
+    go, hp, tr = (t.to(DEV) for t in synth.mano_inputs(B, seed=1))
+    v = rh(global_orient=go, hand_pose=hp, transl=tr).vertices
+    v0 = rh(global_orient=go, hand_pose=hp, transl=torch.zeros_like(tr)).vertices
+    assert (v - v0 - tr[:, None, :]).abs().max().item() < 1e-6
+    part = rh(global_orient=go[1000:1013].contiguous(), hand_pose=hp[1000:1013].contiguous(), transl=tr[1000:1013].contiguous()).vertices
+    assert torch.equal(part, v[1000:1013])
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(1, 1024, 512, True), (5, 2560, 1024, True), (16, 256, 9, False),
+                                        (17, 256, 55, False), (64, 2048, 1024, True), (300, 1024, 128, True),
+                                        (4096, 128, 6, False)])
+def test_linear_vs_torch(M, K, N, relu):
+    r = np.random.default_rng(M + K)
+    x = torch.from_numpy(r.normal(0, 1, (M, K)).astype(np.float32))
+    W = torch.from_numpy(r.normal(0, K ** -0.5, (N, K)).astype(np.float32))
+    b = torch.from_numpy(r.normal(0, 0.1, (N,)).astype(np.float32))
+    ref = torch.nn.functional.linear(x.double(), W.double(), b.double())
+    if relu:
+        ref = ref.relu()
+    y = ops.linear(x.to(DEV), W.to(DEV), b.to(DEV), relu=relu)
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    if N == 9:
+        y2 = ops.linear(x.to(DEV), W.to(DEV), b.to(DEV), add_identity3=True)
+        eye = torch.eye(3).reshape(1, 9)
+        assert (y2.cpu().double() - (ref + eye)).abs().max().item() <= 2e-5
+
+
+def test_mlp_heads_vs_reference_golden():
+    from network.DVQVAE import Decoder, Encoder
+    g = load_golden("mlp")
+    sd = synth.gennet_state_dict(0, with_prior=False)
+    dsd = synth.dvqvae_state_dict(0)
+    dec = Decoder([1024, 256, 55], 2560)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")})
+    pdec = Decoder([1024, 128, 6], 2048)
+    pdec.load_state_dict({k[len("pos_decoder."):]: v for k, v in sd.items() if k.startswith("pos_decoder.")})
+    emb = Encoder([1024, 512], 256)
+    emb.load_state_dict({k[len("emb_0."):]: v for k, v in dsd.items() if k.startswith("emb_0.")})
+    for mod, i, o in ((dec, "dec_in", "dec_out"), (pdec, "pos_in", "pos_out"), (emb, "emb_in", "emb_out")):
+        y = mod.to(DEV)(torch.from_numpy(g[i]).to(DEV))
+        np.testing.assert_allclose(y.cpu().numpy(), g[o], rtol=1e-4, atol=1e-5)
+
+
+def _encoder(prefix, channel, dtype=torch.float32):
+    from network.pointnet_encoder import PointNetEncoder
+    sd = synth.gennet_state_dict(0, with_prior=False)
+    enc = PointNetEncoder(global_feat=True, feature_transform=False, channel=channel)
+    enc.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)})
+    enc.compute_dtype = dtype
+    return enc.to(DEV).eval()
+
+
+def test_pointnet_f32_vs_reference_golden():
+    g = load_golden("pointnet")
+    enc = _encoder("obj_encoder_type.", 4)
+    x4 = torch.cat([torch.from_numpy(g["real_clouds"]), synth.object_clouds(4, 3000, seed=7)], 0)
+    feat, trans, tf = enc(x4.to(DEV))
+    assert tf is None and feat.shape == (6, 1024) and trans.shape == (6, 3, 3)
+    assert rel_err(trans, g["trans4"]) <= 1e-5
+    assert rel_err(feat, g["feat4"]) <= 1e-5
+    enc3 = _encoder("recon_encoder.", 3)
+    for xk, fk, tk in (("x3", "feat3", "trans3"), ("xs", "feats", "transs")):   # N = 778 and N = 83 (ragged chunk)
+        feat, trans, _ = enc3(torch.from_numpy(g[xk]).to(DEV))
+        assert rel_err(trans, g[tk]) <= 1e-5 and rel_err(feat, g[fk]) <= 1e-5
+
+
+def test_pointnet_bf16_tolerance():
+    """bf16 operands for the 64->128->1024 layers, fp32 accumulation.  Stated tolerance:
+    3e-2 of the feature range on the global feature, 2e-2 on the 3x3 transform."""
+    g = load_golden("pointnet")
+    enc = _encoder("obj_encoder_type.", 4, torch.bfloat16)
+    x4 = torch.cat([torch.from_numpy(g["real_clouds"]), synth.object_clouds(4, 3000, seed=7)], 0)
+    feat, trans, _ = enc(x4.to(DEV))
+    e_t, e_f = rel_err(trans, g["trans4"]), rel_err(feat, g["feat4"])
+    print(f"bf16 encoder: trans rel err {e_t:.3e}, feat rel err {e_f:.3e}")
+    assert e_t <= 2e-2 and e_f <= 3e-2
+
+
+@pytest.mark.parametrize("N", [1, 31, 257, 1024, 1025, 3000])
+def test_pointnet_ragged_point_counts(N):
+    sd = synth.gennet_state_dict(0, with_prior=False)
+    enc = _encoder("obj_encoder_pos.", 4)
+    x = synth.object_clouds(3, 3000, seed=3)[:, :, :N].contiguous()
+    ref_f, ref_t = O.pointnet_encoder(x, sd, "obj_encoder_pos.")
+    feat, trans, _ = enc(x.to(DEV))
+    assert rel_err(trans, ref_t) <= 1e-5 and rel_err(feat, ref_f) <= 1e-5
+
+
+def test_pointnet_permutation_and_duplication_invariance():
+    """max-pool properties at full size: permuting or duplicating points of a cloud leaves
+    the global feature bit-identical (the STN sees the same set too)."""
+    enc = _encoder("obj_encoder_type.", 4)
+    x = synth.object_clouds(64, 3000, seed=21).to(DEV)
+    f0, t0, _ = enc(x)
+    perm = torch.randperm(3000, device=DEV, generator=torch.Generator(DEV).manual_seed(0))
+    f1, t1, _ = enc(x[:, :, perm].contiguous())
+    assert torch.equal(f0, f1) and torch.equal(t0, t1)
+    f2, _, _ = enc(torch.cat([x, x[:, :, :500]], dim=2).contiguous())
+    assert torch.equal(f0, f2)

@@ -1,0 +1,111 @@
+"""VQ nearest-codebook kernel vs the CPU oracle and the reference's golden indices."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from dvq_hip import ops, synth
+from oracle import dvq_oracle as O
+from parity import check_vq_rows
+
+pytestmark = pytest.mark.gpu
+VQ_CASES = [(128, 256), (128, 1024), (512, 256), (2048, 256), (8192, 256)]
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("K,D", VQ_CASES)
+@pytest.mark.parametrize("dist", ["A", "B"])
+def test_vq_f32_vs_reference_golden(K, D, dist):
+    g = load_golden("vq")
+    z, E = synth.vq_case(K, D, 4096, dist, seed=0)
+    idx, zq = ops.vq_argmin(z.to(DEV), E.to(DEV))
+    assert idx.dtype == torch.int64 and tuple(idx.shape) == (4096,)
+    idx = idx.cpu()
+    n_diff = check_vq_rows(z, E, idx.numpy(), g[f"idx_{K}_{D}_{dist}"])
+    print(f"K={K} D={D} dist={dist}: {n_diff} near-tie rows differ from the reference")
+    assert torch.equal(zq.cpu(), E[idx])  # z_q is an exact copy of the chosen rows
+
+
+@pytest.mark.parametrize("K,D", VQ_CASES)
+def test_vq_bf16_vs_oracle_on_rounded_inputs(K, D):
+    """bf16 operands, fp32 accumulation: the oracle run on the bf16-rounded inputs is
+    the reference (products of bf16 values are exact in fp32)."""
+    z, E = synth.vq_case(K, D, 4096, "B", seed=0)
+    zb, Eb = z.to(torch.bfloat16), E.to(torch.bfloat16)
+    idx, zq = ops.vq_argmin(zb.to(DEV), Eb.to(DEV))
+    ref, _ = O.vq_forward(zb.float(), Eb.float())
+    check_vq_rows(zb.float(), Eb.float(), idx.cpu().numpy(), ref[:, 0].numpy())
+    assert torch.equal(zq.cpu(), Eb[idx.cpu()])
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 37, 513, 1025])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vq_ragged_sizes(n, dtype):
+    z, E = synth.vq_case(128, 256, max(n, 1), "B", seed=5)
+    z = z[:n].to(dtype)
+    E = E.to(dtype)
+    idx, zq = ops.vq_argmin(z.to(DEV), E.to(DEV))
+    assert idx.shape == (n,) and zq.shape == (n, 256)
+    if n:
+        ref, _ = O.vq_forward(z.float(), E.float())
+        check_vq_rows(z.float(), E.float(), idx.cpu().numpy(), ref[:, 0].numpy())
+
+
+def test_vq_ties_pick_lowest_index_and_odd_K():
+    g = load_golden("vq")
+    z, E = synth.vq_case(128, 256, 37, "A", seed=3)
+    E[5] = E[77]
+    z[0] = E[77]
+    idx, _ = ops.vq_argmin(z.to(DEV), E.to(DEV))
+    assert idx[0].item() == 5
+    check_vq_rows(z, E, idx.cpu().numpy(), g["idx_ragged37"])
+    # K not a multiple of the 32-code tile: padding codes must never win
+    z, E = synth.vq_case(100, 64, 300, "B", seed=6)
+    idx, _ = ops.vq_argmin(z.to(DEV), E.to(DEV))
+    ref, _ = O.vq_forward(z, E)
+    assert idx.max().item() < 100
+    check_vq_rows(z, E, idx.cpu().numpy(), ref[:, 0].numpy())
+    # odd D handled by the generic path
+    z, E = synth.vq_case(96, 48, 200, "B", seed=7)
+    idx, _ = ops.vq_argmin(z.to(DEV), E.to(DEV))
+    ref, _ = O.vq_forward(z, E)
+    check_vq_rows(z, E, idx.cpu().numpy(), ref[:, 0].numpy())
+
+
+def test_vq_prepared_matches_one_shot_and_gather():
+    z, E = synth.vq_case(512, 256, 2000, "B", seed=9)
+    zd, Ed = z.to(DEV), E.to(DEV)
+    ws = ops.vq_prepare(Ed)
+    a, _ = ops.vq_argmin(zd, Ed, want_zq=False, prepared=ws)
+    b, zq = ops.vq_argmin(zd, Ed)
+    assert torch.equal(a, b)
+    wide = torch.zeros(2000, 300, device=DEV)
+    ops.vq_gather(a, Ed, out=wide[:, 20:276])
+    assert torch.equal(wide[:, 20:276], zq) and wide[:, :20].abs().sum() == 0 and wide[:, 276:].abs().sum() == 0
+
+
+def test_vq_full_size_properties():
+    """BASELINE size (1 Mi latents): too big for the oracle in seconds, so check
+    size-independent properties: every row's code is its planted code (dist B is well
+    separated), and the result equals the concatenation of per-slice results."""
+    K, D, n = 512, 256, 1 << 20
+    r = np.random.default_rng(0)
+    E = torch.from_numpy(r.standard_normal((K, D)).astype(np.float32))
+    j = torch.from_numpy(r.integers(0, K, size=n))
+    Ed = E.to(DEV)
+    z = Ed[j.to(DEV)] + 0.3 * torch.randn(n, D, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    idx, _ = ops.vq_argmin(z, Ed, want_zq=False)
+    assert (idx.cpu() == j).float().mean().item() > 0.9999
+    part, _ = ops.vq_argmin(z[12345:12345 + 70001].contiguous(), Ed, want_zq=False)
+    assert torch.equal(part, idx[12345:12345 + 70001])
+    zb = z.to(torch.bfloat16)
+    idx_b, _ = ops.vq_argmin(zb, Ed.to(torch.bfloat16), want_zq=False)
+    assert (idx_b.cpu() == j).float().mean().item() > 0.9999
+
+
+def test_errors_are_raised_not_fatal():
+    z, E = synth.vq_case(128, 256, 8, "A")
+    with pytest.raises(RuntimeError):
+        ops.vq_argmin(z, E)                       # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        ops.vq_argmin(z.to(DEV)[:, :250].contiguous(), E.to(DEV)[:, :250].contiguous())  # D % 16 != 0

@@ -8,27 +8,9 @@ import torch
 from conftest import load_golden
 from dvq_hip import synth
 from oracle import dvq_oracle as O
+from parity import check_vq_rows
 
 VQ_CASES = [(128, 256), (128, 1024), (512, 256), (2048, 256), (8192, 256)]
-
-
-def check_vq_rows(z, E, idx, ref_idx, ulps=4.0):
-    """Index parity rule: equal to the reference wherever the exact (fp64) best-vs-second
-    gap exceeds tau = `ulps` fp32 ulps of |z|^2+max|E|^2; on the remaining near-tie rows
-    the chosen code must itself be within tau of the exact minimum.
-    Returns the number of near-tie rows that differ."""
-    z = z.numpy() if torch.is_tensor(z) else z
-    E = E.numpy() if torch.is_tensor(E) else E
-    idx = np.asarray(idx).reshape(-1)
-    ref_idx = np.asarray(ref_idx).reshape(-1)
-    best, dmin, gap = O.vq_gap_fp64(z, E)
-    tau = O.vq_tau(z, E, ulps)
-    differ = idx != ref_idx
-    assert not np.any(differ & (gap > tau)), f"{int((differ & (gap > tau)).sum())} rows differ outside near-ties"
-    d_at = O.vq_dist_fp64_at(z, E, idx)
-    slack = d_at - dmin
-    assert np.all(slack <= tau + 1e-30), f"chosen code beyond tau of the minimum on {(slack > tau).sum()} rows"
-    return int(differ.sum())
 
 
 @pytest.mark.parametrize("K,D", VQ_CASES)
