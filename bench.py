@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the D-VQVAE grasp-generation path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the whole generation path over one batch of synthetic object
+clouds per GPU: GenNet.gen (2 object encoders -> VQ -> autoregressive prior -> codebook
+lookup -> decoder -> MANO -> hand encoder -> position decoder), the call-site MANO
+(DVQ-VAE/gen_diverse_grasp_obman.py:236-253) and, with several ranks, the RCCL
+all-gather of the generated vertices.  Inputs are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "d-vqvae_amd"))
+sys.path.insert(0, ROOT)
+
+from dvq_hip import ops, parallel, synth  # noqa: E402
+from dvq_hip.pipeline import GraspGenerator  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X
+FLOP_PER_POINT = {3: 2 * (3 * 64 + 64 * 128 + 128 * 1024), 4: 2 * (4 * 64 + 64 * 128 + 128 * 1024)}
+
+
+def timed_steps(fn, steps, warmup, device, barrier):
+    for _ in range(warmup):
+        fn()
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    torch.cuda.synchronize(device)
+    return time.perf_counter() - t0
+
+
+def kernel_stats(name_prefix):
+    """(avg ms, launches, work tuple) over launches recorded by ops.TIMERS."""
+    best = None
+    for name, recs in (ops.TIMERS or {}).items():
+        if name.startswith(name_prefix):
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            cand = (sum(ms) / len(ms), len(ms), recs[0][2], name)
+            if best is None or cand[0] * cand[1] > best[0] * best[1]:
+                best = cand
+    return best
+
+
+def vq_microbench(device, n=1 << 20, iters=5):
+    """Isolated nearest-codebook search: 1 Mi latents, reference codebook shapes + K sweep."""
+    out = []
+    for dtype, name in ((torch.bfloat16, "bf16"), (torch.float32, "fp32")):
+        for K, D in ((128, 256), (512, 256), (2048, 256), (8192, 256)):
+            g = torch.Generator(device).manual_seed(K)
+            E = torch.randn(K, D, device=device, generator=g)
+            j = torch.randint(0, K, (n,), device=device, generator=g)
+            z = (E[j] + 0.3 * torch.randn(n, D, device=device, generator=g)).to(dtype)
+            E = E.to(dtype)
+            del j
+            ws = ops.vq_prepare(E)
+            ops.vq_argmin(z, E, want_zq=False, prepared=ws)
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                ops.vq_argmin(z, E, want_zq=False, prepared=ws)
+            e1.record()
+            torch.cuda.synchronize(device)
+            ms = e0.elapsed_time(e1) / iters
+            flops = 2.0 * n * K * D
+            nbytes = n * D * z.element_size() + K * D * z.element_size() + 8 * n
+            out.append({"K": K, "D": D, "dtype": name, "n": n, "ms": round(ms, 4),
+                        "tflops": round(flops / ms / 1e9, 1),
+                        "frac_mfma_peak": round(flops / ms / 1e9 / PEAK_TFLOPS[name], 4),
+                        "hbm_gbs": round(nbytes / ms / 1e6, 1),
+                        "mlatents_per_s": round(n / ms / 1e3, 1)})
+            del z, E, ws
+    return out
+
+
+def cpu_baseline(with_prior, budget_s=12.0, batch=16):
+    """The CPU oracle (op-for-op restatement of the reference's PyTorch path) on this box's
+    host cores, on a bounded sample of the same workload."""
+    from oracle import dvq_oracle as O
+    sd = synth.gennet_state_dict(0, with_prior=True)
+    sd.update(synth.mano_state_dict(0, batch_size=1, prefix="rh_mano."))
+    objs = synth.object_clouds(batch, 3000, seed=1234)
+    forced = None if with_prior else torch.randint(0, 128, (batch, 3, 3), generator=torch.Generator().manual_seed(0))
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        O.generate_grasps(sd, objs[:2], x_tilde=None if forced is None else forced[:2], generator=gen)   # warm-up
+        done, t0 = 0, time.perf_counter()
+        while True:
+            O.generate_grasps(sd, objs, x_tilde=forced, generator=gen)
+            done += batch
+            el = time.perf_counter() - t0
+            if el >= budget_s or el + el / (done / batch) > 30.0:
+                break
+    return {"value": round(done / el, 3), "unit": "grasps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} grasps in batches of {batch} x 3000-pt clouds, fp32 torch CPU ops, "
+                      f"prior {'sampled' if with_prior else 'teacher-forced'}, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="object clouds per GPU and step")
+    ap.add_argument("--points", type=int, default=3000)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--prior", choices=["sampled", "forced"], default="sampled",
+                    help="'forced' feeds given part indices instead of running the autoregressive prior")
+    ap.add_argument("--no-extras", action="store_true", help="skip the VQ microbench, the variants and the CPU baseline")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    B, N = args.batch, args.points
+    tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    gen = GraspGenerator.synthetic(device, seed=0, dtype=tdtype, with_prior=True)
+    obj = synth.object_clouds_device(B, N, 1234 + rank, device)
+    first_id = rank * B
+    forced = torch.randint(0, 128, (B, 3, 3), device=device, generator=torch.Generator(device).manual_seed(rank))
+
+    def step(prior=args.prior):
+        out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None,
+                           gather=world > 1, n_total=world * B)
+        return out["vertices"]
+
+    ops.enable_timers(True)
+    elapsed = timed_steps(step, args.steps, args.warmup, device, barrier)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ks = kernel_stats(f"pointnet_mlp_max[C=4,N={N}]")
+    ops.enable_timers(False)
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        result = {
+            "metric": "grasps generated/sec", "value": round(value, 1), "unit": "grasps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "end-to-end GenNet.gen (2 object encoders -> VQ -> prior -> decoder -> MANO -> hand "
+                                   "encoder -> pos decoder) + call-site MANO LBS" +
+                                   (" + RCCL all-gather of vertices" if world > 1 else ""),
+                       "objects_per_gpu": B, "points_per_object": N, "global_batch": world * B,
+                       "prior": args.prior, "weights": "random-init (seed 0), MANO-shaped synthetic hand model",
+                       "parallelism": f"dp{world}"},
+        }
+        if ks is not None:
+            avg_ms, launches, (kb, kc, kn), name = ks
+            flops = float(kb) * kn * FLOP_PER_POINT[kc]
+            ach = flops / avg_ms / 1e9
+            result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1),
+                                  "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                  "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                                  "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
+                                  "flop_per_launch": flops}
+
+    if not args.no_extras and world == 1:
+        # variants of the same step, the VQ microbench and the CPU baseline (rank 0, N=1 only)
+        variants = {}
+        other = "forced" if args.prior == "sampled" else "sampled"
+        el = timed_steps(lambda: step(other), max(2, args.steps // 2), 1, device, barrier)
+        variants[f"{args.dtype}_prior_{other}"] = round(B * max(2, args.steps // 2) / el, 1)
+        odt = torch.float32 if args.dtype == "bf16" else torch.bfloat16
+        import dvq_hip
+        dvq_hip.set_compute_dtype(gen.model, odt)
+        el = timed_steps(lambda: step("forced"), 2, 1, device, barrier)
+        variants[f"{'fp32' if args.dtype == 'bf16' else 'bf16'}_prior_forced"] = round(B * 2 / el, 1)
+        dvq_hip.set_compute_dtype(gen.model, tdtype)
+        result["variants_grasps_per_s"] = variants
+        del obj
+        torch.cuda.empty_cache()
+        result["vq_argmin"] = vq_microbench(device)
+        result["cpu_baseline"] = cpu_baseline(args.prior == "sampled")
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

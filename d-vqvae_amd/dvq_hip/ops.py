@@ -15,6 +15,32 @@ from . import _lib
 from ._lib import DVQ_BF16, DVQ_F32, DvqManoConsts, DvqPointMlp
 
 
+# Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
+# roofline figure): TIMERS[name] collects (start_event, end_event, work) per launch.
+TIMERS = None
+
+
+def enable_timers(on: bool = True):
+    global TIMERS
+    TIMERS = {} if on else None
+
+
+class _timed:
+    def __init__(self, name, work, ref):
+        self.name, self.work, self.ref = name, work, ref
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.ref.device))
+
+    def __exit__(self, *exc):
+        if TIMERS is not None:
+            self.e1.record(torch.cuda.current_stream(self.ref.device))
+            TIMERS.setdefault(self.name, []).append((self.e0, self.e1, self.work))
+
+
 def _p(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -133,7 +159,7 @@ def pointnet_mlp_max(x: torch.Tensor, trans: Optional[torch.Tensor], w: dict, re
     feat = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
     s = DvqPointMlp(w["a1"].data_ptr(), w["c1"].data_ptr(), w["a2"].data_ptr(), w["c2"].data_ptr(),
                     w["w3p"].data_ptr(), w["c3"].data_ptr())
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed(f"pointnet_mlp_max[C={C},N={N}]", (B, C, N), x):
         rc = _lib.load().dvq_pointnet_mlp_max(_p(x), _p(trans), B, C, N, ctypes.byref(s), int(relu3), dtype_code,
                                               _p(feat), _stream(x))
     _lib.check(rc, "dvq_pointnet_mlp_max")
@@ -171,7 +197,7 @@ def mano_lbs(global_orient, hand_pose, transl, consts: DvqManoConsts, n_verts: i
     verts = torch.empty(B, n_verts, 3, dtype=torch.float32, device=dev)
     joints = torch.empty(B, 16, 3, dtype=torch.float32, device=dev) if want_joints else None
     full = torch.empty(B, 48, dtype=torch.float32, device=dev) if want_full_pose else None
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("mano_lbs", (B,), hand_pose):
         rc = _lib.load().dvq_mano_lbs(_p(global_orient), _p(hand_pose), _p(transl), B, ctypes.byref(consts),
                                       _p(verts), _p(joints), _p(full), _stream(hand_pose))
     _lib.check(rc, "dvq_mano_lbs")

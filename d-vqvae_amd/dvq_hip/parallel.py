@@ -1,0 +1,47 @@
+"""Data-parallel sharding of grasp generation: one process per GPU.
+
+Objects are independent (eval-mode BatchNorm, no cross-sample operation), so rank r of G
+takes the contiguous slice [r*ceil(n/G), ...) of the object list, weights are replicated
+and nothing is exchanged while computing.  The only collective is the all-gather of the
+finished outputs (vertices, 9336 B per grasp): RCCL over xGMI when the process group is
+'nccl', gloo in the CPU tests.
+"""
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """[begin, end) of the objects rank `rank` owns; slices are contiguous, ordered by rank
+    and differ in size by at most one block of ceil(n/world)."""
+    per = (n + world_size - 1) // world_size
+    b = min(n, rank * per)
+    return b, min(n, b + per)
+
+
+def gather_rows(t: torch.Tensor, n_total: int = None) -> torch.Tensor:
+    """All-gather equally sized per-rank row blocks [m, ...] into [world*m, ...] (out of place);
+    `n_total` trims padding rows when the last shard was short."""
+    rank, ws = world()
+    if ws == 1:
+        return t if n_total is None else t[:n_total]
+    t = t.contiguous()
+    out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out if n_total is None else out[:n_total]
+
+
+def pad_rows(t: torch.Tensor, m: int) -> torch.Tensor:
+    """Pad a short last shard to m rows (repeating the last row) so all ranks gather equal blocks."""
+    if t.shape[0] == m:
+        return t
+    if t.shape[0] == 0:
+        return torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    return torch.cat([t, t[-1:].expand(m - t.shape[0], *t.shape[1:])], 0)

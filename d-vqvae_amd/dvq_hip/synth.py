@@ -290,3 +290,27 @@ def mano_inputs(B: int, seed: int = 0):
     hp = (r.standard_normal(size=(B, 45)) * 2.3).astype(np.float32)
     tr = (np.array(OBJ_TRANSLATION) + r.normal(0, 0.03, size=(B, 3))).astype(np.float32)
     return torch.from_numpy(go), torch.from_numpy(hp), torch.from_numpy(tr)
+
+
+def object_clouds_device(B: int, N: int, seed: int, device) -> torch.Tensor:
+    """Same family of clouds as object_clouds(), generated on the device with torch's
+    generator (fast enough for B = 4096; not bit-identical to the numpy recipe)."""
+    g = torch.Generator(device).manual_seed(int(seed))
+    h = torch.rand(B, 1, 3, device=device, generator=g) * 0.11 + 0.02
+    p = (torch.rand(B, N, 3, device=device, generator=g) * 2 - 1) * h
+    face = torch.randint(0, 3, (B, N, 1), device=device, generator=g)
+    sign = torch.randint(0, 2, (B, N, 1), device=device, generator=g).float() * 2 - 1
+    p.scatter_(2, face, sign * torch.gather(h.expand(B, N, 3), 2, face))
+    diag = (p.amax(1) - p.amin(1)).norm(dim=1)
+    a = torch.rand(B, 3, device=device, generator=g) * (2 * math.pi)
+    cx, sx, cy, sy, cz, sz = a[:, 0].cos(), a[:, 0].sin(), a[:, 1].cos(), a[:, 1].sin(), a[:, 2].cos(), a[:, 2].sin()
+    o, z = torch.ones_like(cx), torch.zeros_like(cx)
+    Rx = torch.stack([o, z, z, z, cx, -sx, z, sx, cx], 1).view(B, 3, 3)
+    Ry = torch.stack([cy, z, sy, z, o, z, -sy, z, cy], 1).view(B, 3, 3)
+    Rz = torch.stack([cz, -sz, z, sz, cz, z, z, z, o], 1).view(B, 3, 3)
+    R = Rx @ Ry @ Rz
+    p = p @ R.transpose(1, 2) + torch.tensor(OBJ_TRANSLATION, device=device)
+    out = torch.empty(B, 4, N, device=device)
+    out[:, :3] = p.transpose(1, 2)
+    out[:, 3] = diag[:, None]
+    return out.contiguous()

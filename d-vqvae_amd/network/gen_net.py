@@ -7,7 +7,8 @@ reference applied to obj[b:b+1].  Tensors stay on the input's device.
 
 gen(obj, x_tilde=None, generator=None): `x_tilde` (int64 [B,3,3]) bypasses the
 autoregressive prior with given part indices (teacher forcing); otherwise the prior is
-sampled, optionally with a torch.Generator for reproducibility.
+sampled, optionally with a torch.Generator, or by inverse CDF from given `uniforms`
+[B,9] (dvq_hip.rng: reproducible for any sharding of the batch).
 """
 import torch
 import torch.nn as nn
@@ -59,7 +60,7 @@ class GenNet(nn.Module):
         pos = self.pos_decoder(torch.cat((hand_feat, obj_feat_pos), 1)).view(B, 6)
         return recon, pos
 
-    def gen(self, obj, x_tilde=None, generator=None):
+    def gen(self, obj, x_tilde=None, generator=None, uniforms=None):
         if self.rh_mano is None:
             raise RuntimeError("GenNet.gen: call set_rh_mano(mano_layer) first")
         B = obj.size()[0]
@@ -68,7 +69,8 @@ class GenNet(nn.Module):
         idx6, _obj_emb = self.vqvae6.inference(obj_feat_type)
         if x_tilde is None:
             label = idx6[:, 0]
-            x_tilde = self.GatedPixelCNN.generate(None, label, shape=(3, 3), batch_size=B, generator=generator)
+            x_tilde = self.GatedPixelCNN.generate(None, label, shape=(3, 3), batch_size=B, generator=generator,
+                                                  uniforms=uniforms)
         part_idx = torch.stack([x_tilde[:, r, c] for r, c in PART_CELLS], dim=1).to(torch.int64)
         self.last_x_tilde = x_tilde
         self.last_idx6 = idx6

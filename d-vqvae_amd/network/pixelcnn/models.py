@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from dvq_hip.rng import sample_rows
+
 
 def weights_init(m):
     classname = m.__class__.__name__
@@ -82,7 +84,8 @@ class GatedPixelCNN(nn.Module):
         return self.output_conv(x_h)
 
     @torch.no_grad()
-    def generate(self, x_start, label, shape=(3, 3), batch_size=64, generator=None, return_probs=False):
+    def generate(self, x_start, label, shape=(3, 3), batch_size=64, generator=None, return_probs=False,
+                 uniforms=None):
         """models.py:176-198: one full forward per grid cell, cell (i,j) drawn from
         softmax(logits[:, :, i, j]).  `x_start` is accepted and ignored, as in the reference."""
         param = next(self.parameters())
@@ -95,7 +98,10 @@ class GatedPixelCNN(nn.Module):
                 probs = probs / probs.sum(dim=1, keepdim=True)
                 if return_probs:
                     probs_all.append(probs)
-                x[:, i, j] = probs.multinomial(1, generator=generator).squeeze(1)
+                if uniforms is not None:
+                    x[:, i, j] = sample_rows(probs, uniforms[:, i * shape[1] + j])
+                else:
+                    x[:, i, j] = probs.multinomial(1, generator=generator).squeeze(1)
         if return_probs:
             return x, torch.stack(probs_all, 1)
         return x
