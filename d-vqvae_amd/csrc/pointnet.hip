@@ -35,9 +35,10 @@ constexpr int kCt = kC3 / 32;  // 32 output-channel tiles
 
 template <int DT> struct PnCfg;
 template <> struct PnCfg<DVQ_BF16> {
-    static constexpr int NP = 4;          // 32-point tiles per wave and chunk
+    static constexpr int NP = 2;          // 32-point tiles per wave and chunk
     static constexpr int UPC = 8;         // 1-KiB conv3 weight units per channel tile (4 row tiles x 2 k-steps)
-    static constexpr int CPS = 8;         // channel tiles per LDS stage (64 KiB)
+    static constexpr int CPS = 2;         // channel tiles per LDS stage (16 KiB): 54 KiB of LDS, two blocks per CU
+    static constexpr int MIN_WAVES = 4;   // waves per SIMD to aim the register allocation at
     static constexpr int A2_UNITS = 16;   // conv2 weights: 4 row tiles x 4 k-steps
     static constexpr int XR = 8;          // 4-register groups of conv2 output per point tile (8 frags x 4 VGPRs)
 };
@@ -45,6 +46,7 @@ template <> struct PnCfg<DVQ_F32> {
     static constexpr int NP = 2;
     static constexpr int UPC = 16;        // 4 row tiles x 4 groups of 4 k-steps
     static constexpr int CPS = 2;         // 32 KiB per stage
+    static constexpr int MIN_WAVES = 2;
     static constexpr int A2_UNITS = 32;   // 4 row tiles x 8 groups of 4 k-steps
     static constexpr int XR = 16;
 };
@@ -91,8 +93,108 @@ __global__ void pn_pack_w3_kernel(const float* __restrict__ a3, uint4* __restric
     out[t] = v;
 }
 
+// conv1 (VALU) + conv2 (MFMA) for one tile of 32 points: lane (r,h) owns point `n`.
+// Leaves relu(conv2) in `xb` (bf16, 8 A-operand fragments) or `xf` (fp32, 64 values) in the
+// k order conv3 consumes.
 template <int DT, int C>
-__global__ __launch_bounds__(kPnThreads) void pointnet_mlp_max_kernel(
+__device__ __forceinline__ void pn_point_tile(const float* __restrict__ xb_, int N, int n, bool has_trans, const float (&T)[9],
+                                              const float* a1s, const float* c1s, const char* a2s, const float* c2s,
+                                              int lane, int h, bf16x8 (&Xb_np)[8], float (&Xf_np)[64]) {
+    const float* xb = xb_;
+    float p[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[c] = c < C ? xb[(int64_t)c * N + n] : 0.f;
+    if (has_trans) {  // xyz' = xyz * T  (pointnet_encoder.py:146)
+        const float q0 = p[0], q1 = p[1], q2 = p[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float v = q0 * T[j];
+            v = __builtin_fmaf(q1, T[3 + j], v);
+            v = __builtin_fmaf(q2, T[6 + j], v);
+            p[j] = v;
+        }
+    }
+    // conv1: channels 32h .. 32h+31 of this lane's point, 4 at a time
+    auto conv1_4 = [&](int t4, float (&o)[4]) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(c1s + 32 * h + 4 * t4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(a1s + (32 * h + 4 * t4 + q) * 4);
+            float v = w[0] * p[0];
+            v = __builtin_fmaf(w[1], p[1], v);
+            v = __builtin_fmaf(w[2], p[2], v);
+            if (C > 3) v = __builtin_fmaf(w[3], p[3], v);
+            v += bias[q];
+            o[q] = v > 0.f ? v : 0.f;
+        }
+    };
+    if constexpr (DT == DVQ_BF16) {
+        bf16x8 hb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float lo[4], hi[4];
+            conv1_4(2 * s, lo);
+            conv1_4(2 * s + 1, hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hb[s][j] = static_cast<__bf16>(lo[j]); hb[s][4 + j] = static_cast<__bf16>(hi[j]); }
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(c2s + 32 * t2 + 8 * g + 4 * h);
+                acc[4 * g + 0] = bias[0]; acc[4 * g + 1] = bias[1]; acc[4 * g + 2] = bias[2]; acc[4 * g + 3] = bias[3];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(a2s + ((t2 * 4 + s) * 64 + lane) * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = acc[8 * s + j];
+                    Xb_np[t2 * 2 + s][j] = static_cast<__bf16>(v > 0.f ? v : 0.f);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        float h1[32];
+#pragma unroll
+        for (int t4 = 0; t4 < 8; ++t4) {
+            float o[4];
+            conv1_4(t4, o);
+            h1[4 * t4 + 0] = o[0]; h1[4 * t4 + 1] = o[1]; h1[4 * t4 + 2] = o[2]; h1[4 * t4 + 3] = o[3];
+            // keep the scheduler from hoisting all 40 weight reads (160 registers) to the top
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(c2s + 32 * t2 + 8 * g + 4 * h);
+                acc[4 * g + 0] = bias[0]; acc[4 * g + 1] = bias[1]; acc[4 * g + 2] = bias[2]; acc[4 * g + 3] = bias[3];
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 8; ++t4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(a2s + ((t2 * 8 + t4) * 64 + lane) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], h1[4 * t4 + q], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = acc[i];
+                Xf_np[t2 * 16 + i] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+
+template <int DT, int C>
+__global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp_max_kernel(
     const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
     const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
     const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat) {
@@ -162,90 +264,20 @@ __global__ __launch_bounds__(kPnThreads) void pointnet_mlp_max_kernel(
             for (int u = wave; u < UNITS; u += kPnWaves) glds16(w3p + (int64_t)u * 1024 + lane * 16, w3s + u * 1024);
         }
         // ---- conv1 + conv2 for this wave's NP point tiles -> X (conv3 A fragments)
-        bf16x8 Xb[(DT == DVQ_BF16) ? NP : 1][(DT == DVQ_BF16) ? 8 : 1];
-        float Xf[(DT == DVQ_F32) ? NP : 1][(DT == DVQ_F32) ? 64 : 1];
-#pragma unroll
-        for (int np = 0; np < NP; ++np) {
-            int n = chunk * PTS_PER_CHUNK + (wave * NP + np) * 32 + r;
-            if (n >= N) n = N - 1;  // duplicate the last point: a duplicate cannot change a max
-            float p[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) p[c] = c < C ? xb[(int64_t)c * N + n] : 0.f;
-            if (has_trans) {  // xyz' = xyz * T  (pointnet_encoder.py:146)
-                const float q0 = p[0], q1 = p[1], q2 = p[2];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    float v = q0 * T[j];
-                    v = __builtin_fmaf(q1, T[3 + j], v);
-                    v = __builtin_fmaf(q2, T[6 + j], v);
-                    p[j] = v;
-                }
-            }
-            // conv1: channels 32h .. 32h+31 of this lane's point
-            float h1[32];
-#pragma unroll
-            for (int t4 = 0; t4 < 8; ++t4) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(c1s + 32 * h + 4 * t4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(a1s + (32 * h + 4 * t4 + q) * 4);
-                    float v = w[0] * p[0];
-                    v = __builtin_fmaf(w[1], p[1], v);
-                    v = __builtin_fmaf(w[2], p[2], v);
-                    if (C > 3) v = __builtin_fmaf(w[3], p[3], v);
-                    v += bias[q];
-                    h1[4 * t4 + q] = v > 0.f ? v : 0.f;
-                }
-            }
-            if constexpr (DT == DVQ_BF16) {
-                bf16x8 hb[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) hb[s][j] = static_cast<__bf16>(h1[8 * s + j]);
-#pragma unroll
-                for (int t2 = 0; t2 < 4; ++t2) {
-                    f32x16 acc;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4*>(c2s + 32 * t2 + 8 * g + 4 * h);
-                        acc[4 * g + 0] = bias[0]; acc[4 * g + 1] = bias[1]; acc[4 * g + 2] = bias[2]; acc[4 * g + 3] = bias[3];
-                    }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(a2s + ((t2 * 4 + s) * 64 + lane) * 16);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float v = acc[8 * s + j];
-                            Xb[np][t2 * 2 + s][j] = static_cast<__bf16>(v > 0.f ? v : 0.f);
-                        }
-                }
-            } else {
-#pragma unroll
-                for (int t2 = 0; t2 < 4; ++t2) {
-                    f32x16 acc;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4*>(c2s + 32 * t2 + 8 * g + 4 * h);
-                        acc[4 * g + 0] = bias[0]; acc[4 * g + 1] = bias[1]; acc[4 * g + 2] = bias[2]; acc[4 * g + 3] = bias[3];
-                    }
-#pragma unroll
-                    for (int t4 = 0; t4 < 8; ++t4) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(a2s + ((t2 * 8 + t4) * 64 + lane) * 16);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], h1[4 * t4 + q], acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float v = acc[i];
-                        Xf[np][t2 * 16 + i] = v > 0.f ? v : 0.f;
-                    }
-                }
-            }
+        bf16x8 Xb[(DT == DVQ_BF16) ? NP : 1][8];
+        float Xf[(DT == DVQ_F32) ? NP : 1][64];
+        {
+            const int nbase = chunk * PTS_PER_CHUNK + wave * NP * 32 + r;
+            // one call per point tile, spelled out so that every fragment index is a constant
+#define DVQ_PN_TILE(np)                                                                                           \
+    if constexpr (NP > np) {                                                                                      \
+        int n = nbase + np * 32;                                                                                  \
+        if (n >= N) n = N - 1; /* duplicate the last point: a duplicate cannot change a max */                    \
+        pn_point_tile<DT, C>(xb, N, n, has_trans, T, a1s, c1s, a2s, c2s, lane, h, Xb[(DT == DVQ_BF16) ? np : 0],  \
+                             Xf[(DT == DVQ_F32) ? np : 0]);                                                       \
+    }
+            DVQ_PN_TILE(0) DVQ_PN_TILE(1) DVQ_PN_TILE(2) DVQ_PN_TILE(3)
+#undef DVQ_PN_TILE
         }
         __syncthreads();  // stage 0 has landed (the barrier drains the direct-to-LDS loads)
 

@@ -66,6 +66,7 @@ _ALLOWED = {
     ("numpy", "ndarray"), ("numpy", "dtype"),
     ("scipy.sparse.csc", "csc_matrix"), ("scipy.sparse._csc", "csc_matrix"),
     ("scipy.sparse.csr", "csr_matrix"), ("scipy.sparse._csr", "csr_matrix"),
+    ("_codecs", "encode"),     # how Python 3 writes an array's bytes at protocol 2
     ("copy_reg", "_reconstructor"), ("copyreg", "_reconstructor"), ("__builtin__", "object"), ("builtins", "object"),
 }
 _CHUMPY = {("chumpy.ch", "Ch"), ("chumpy.reordering", "Select"), ("chumpy.ch", "MatVecMult"), ("chumpy.reordering", "Reorder")}

@@ -22,7 +22,9 @@ def uniforms(sample_ids: torch.Tensor, n_cells: int, seed: int = 0) -> torch.Ten
     """float64 uniforms in [0,1) of shape [len(sample_ids), n_cells]."""
     ids = sample_ids.to(torch.int64).reshape(-1, 1)
     cells = torch.arange(n_cells, dtype=torch.int64, device=ids.device).reshape(1, -1)
-    ctr = ids * 1024 + cells + (int(seed) * -7046029254386353131)   # 0x9E3779B97F4A7C15 stride per seed
+    off = (int(seed) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF      # golden-ratio stride per seed, wrapped
+    off = off - (1 << 64) if off >= (1 << 63) else off
+    ctr = ids * 1024 + cells + off
     bits = _mix(_mix(ctr) + 0x632BE59BD9B4E019)
     return ((bits >> 11) & _MASK53).to(torch.float64) / float(1 << 53)
 

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Kernel-level timings for tuning: python tools/kbench.py [pointnet] [vq] [mano] [linear]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "d-vqvae_amd"))
+from dvq_hip import ops, synth  # noqa: E402
+from dvq_hip._lib import DVQ_BF16, DVQ_F32  # noqa: E402
+
+dev = torch.device("cuda", 0)
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def pointnet():
+    from network.pointnet_encoder import PointNetEncoder
+    sd = synth.gennet_state_dict(0, with_prior=False)
+    for C, N, B in ((4, 3000, 4096), (3, 778, 4096), (4, 3000, 64), (4, 3000, 1)):
+        enc = PointNetEncoder(channel=C)
+        pre = "obj_encoder_type." if C == 4 else "recon_encoder."
+        enc.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+        enc = enc.to(dev).eval()
+        x = torch.randn(B, C, N, device=dev) * 0.1
+        for dt, code, peak in ((torch.bfloat16, DVQ_BF16, 2500.0), (torch.float32, DVQ_F32, 157.3)):
+            enc.compute_dtype = dt
+            w = enc._packed().as_dict()
+            trans = torch.eye(3, device=dev).repeat(B, 1, 1).contiguous()
+            ms = timeit(lambda: ops.pointnet_mlp_max(x, trans, w, False, code), iters=5 if dt == torch.float32 else 10)
+            fl = 2.0 * B * N * (C * 64 + 64 * 128 + 128 * 1024)
+            print(f"pointnet_mlp_max C={C} N={N} B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  "
+                  f"{fl / ms / 1e9 / peak * 100:5.1f}% of peak", flush=True)
+
+
+def vq():
+    n = 1 << 20
+    for dt, name, peak in ((torch.bfloat16, "bf16", 2500.0), (torch.float32, "fp32", 157.3)):
+        for K, D in ((128, 256), (512, 256), (2048, 256), (8192, 256), (128, 1024)):
+            nn = n if D == 256 else n // 4
+            g = torch.Generator(dev).manual_seed(K)
+            E = torch.randn(K, D, device=dev, generator=g)
+            z = (E[torch.randint(0, K, (nn,), device=dev, generator=g)] + 0.3 * torch.randn(nn, D, device=dev, generator=g)).to(dt)
+            E = E.to(dt)
+            ws = ops.vq_prepare(E)
+            ms = timeit(lambda: ops.vq_argmin(z, E, want_zq=False, prepared=ws), iters=5)
+            fl = 2.0 * nn * K * D
+            by = nn * D * z.element_size() + 8 * nn
+            print(f"vq_argmin K={K:5d} D={D:4d} n={nn} {name}: {ms:8.4f} ms  {fl / ms / 1e9:7.1f} TFLOP/s {fl / ms / 1e9 / peak * 100:5.1f}% of peak"
+                  f"  {by / ms / 1e6:7.1f} GB/s", flush=True)
+            del z, E, ws
+
+
+def mano():
+    import mano as M
+    from dvq_hip.mano_io import Struct
+    rh = M.MANO('', data_struct=Struct(**synth.mano_model_data(0)), use_pca=True, num_pca_comps=45, batch_size=1,
+                flat_hand_mean=True).to(dev).eval()
+    for B in (1, 64, 4096, 32768):
+        go, hp, tr = (t.to(dev) for t in synth.mano_inputs(B, seed=1))
+        ms = timeit(lambda: rh(global_orient=go, hand_pose=hp, transl=tr))
+        print(f"mano B={B}: {ms:.4f} ms  {B * 778 * 12 / ms / 1e6:.1f} GB/s out", flush=True)
+
+
+def linear():
+    for M_, K, N in ((4096, 2560, 1024), (4096, 1024, 256), (4096, 1024, 512), (4096, 2048, 1024), (1, 2560, 1024), (16, 2560, 1024)):
+        x = torch.randn(M_, K, device=dev)
+        W = torch.randn(N, K, device=dev)
+        b = torch.randn(N, device=dev)
+        ms = timeit(lambda: ops.linear(x, W, b, relu=True))
+        print(f"linear M={M_} K={K} N={N}: {ms:.4f} ms  {2.0 * M_ * K * N / ms / 1e9:.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["pointnet", "vq", "mano", "linear"]
+    for w in which:
+        globals()[w]()
