@@ -1,13 +1,26 @@
 """Class-conditional GatedPixelCNN prior over the 3x3 grid of code indices.
 
 Mirrors DVQ-VAE/network/pixelcnn/models.py:21-198 (same module tree, 140 state_dict keys
-for GatedPixelCNN(512, 512, 15)).  This part of the path runs on stock PyTorch-ROCm
-operators; it has no hand-written kernel yet.  Differences from the reference, none
-visible at its only supported batch size of 1:
-  * the mask-'A' zeroing (make_causal) is applied to a masked copy of the weights instead
-    of overwriting the parameters on every forward;
-  * sampling normalises each row by its own sum (the reference divides by the sum over the
-    whole batch, models.py:194) and accepts a torch.Generator.
+for GatedPixelCNN(512, 512, 15)); forward(x, label) returns the same logits.
+
+generate() draws the grid cell by cell like the reference (models.py:176-198) but does
+not re-run the whole network nine times.  The masked convolutions are causal -- the
+logits of cell (i,j) depend only on rows < i and on cells (i, <j) -- so every
+activation the reference recomputes for a finished cell is identical in all later
+passes.  Here each activation is computed once:
+  * when a grid row starts, the vertical stack of that whole row (all 15 layers), which
+    only sees rows above it, and its 1x1 projection into the horizontal stack;
+  * per cell, the horizontal stack at that single position, from the cached
+    activations of its left neighbour, then the output head and one sample.
+That is one network evaluation per grid instead of nine, with every product a plain
+[batch, K] x [K, N] matrix product over the whole batch.  Activations are kept
+position-major ([cell][batch][channel]) so each product reads contiguous rows.
+
+Differences from the reference, none visible at its only supported batch size of 1:
+the mask-'A' zeroing is applied to a masked copy of the weights instead of overwriting
+the parameters on every forward; sampling normalises each row by its own sum (the
+reference divides by the sum over the whole batch, models.py:194) and accepts a
+torch.Generator or explicit uniforms.
 """
 import torch
 import torch.nn as nn
@@ -64,6 +77,33 @@ class GatedMaskedConv2d(nn.Module):
         return out_v, out_h
 
 
+class _Taps:
+    """Per-layer weights re-laid for the incremental evaluation: one [K, N] matrix per
+    kernel tap that can touch the grid, already transposed for row-major products."""
+
+    def __init__(self, layer: GatedMaskedConv2d, dtype):
+        k = layer.kernel
+        wv = layer.vert_stack.weight.detach()      # [2d, d, k//2+1, k]
+        wh = layer.horiz_stack.weight.detach()     # [2d, d, 1, k//2+1]
+        rows = k // 2 + 1
+        if layer.mask_type == 'A':                 # last kernel row / column is masked out (models.py:61-63)
+            vrows, hcols = range(rows - 1), range(rows - 1)
+        else:
+            vrows, hcols = range(rows), range(rows)
+        # vertical tap (a, b): input row i - k//2 + a, input col j - k//2 + b
+        self.vert = {(a - k // 2, b - k // 2): wv[:, :, a, b].t().contiguous().to(dtype) for a in vrows for b in range(k)}
+        # horizontal tap b: input col j - k//2 + b
+        self.horiz = {b - k // 2: wh[:, :, 0, b].t().contiguous().to(dtype) for b in hcols}
+        self.vert_bias = layer.vert_stack.bias.detach().float()
+        self.horiz_bias = layer.horiz_stack.bias.detach().float()
+        self.v2h = layer.vert_to_horiz.weight.detach()[:, :, 0, 0].t().contiguous().to(dtype)
+        self.v2h_bias = layer.vert_to_horiz.bias.detach().float()
+        self.resid = layer.horiz_resid.weight.detach()[:, :, 0, 0].t().contiguous().to(dtype)
+        self.resid_bias = layer.horiz_resid.bias.detach().float()
+        self.cond = layer.class_cond_embedding.weight.detach().float()
+        self.residual = layer.residual
+
+
 class GatedPixelCNN(nn.Module):
     def __init__(self, input_dim=256, dim=128, n_layers=15, n_classes=128):
         super().__init__()
@@ -74,6 +114,9 @@ class GatedPixelCNN(nn.Module):
             self.layers.append(GatedMaskedConv2d('A' if i == 0 else 'B', dim, 5 if i == 0 else 3, i != 0, n_classes))
         self.output_conv = nn.Sequential(nn.Conv2d(dim, 2048, 1), nn.ReLU(True), nn.Conv2d(2048, input_dim, 1))
         self.apply(weights_init)
+        self.compute_dtype = torch.float32     # operand precision of the matrix products in generate()
+        self._taps_key = None
+        self._taps = None
 
     def forward(self, x, label):
         shp = x.size() + (-1,)
@@ -83,25 +126,123 @@ class GatedPixelCNN(nn.Module):
             x_v, x_h = layer(x_v, x_h, label)
         return self.output_conv(x_h)
 
+    # ------------------------------------------------------------------ sampling
+    def _prepared(self):
+        key = (tuple((p.data_ptr(), p._version) for p in self.parameters()), self.compute_dtype)
+        if key != self._taps_key:
+            dt = self.compute_dtype
+            head = (self.output_conv[0].weight.detach()[:, :, 0, 0].t().contiguous().to(dt),
+                    self.output_conv[0].bias.detach().float(),
+                    self.output_conv[2].weight.detach()[:, :, 0, 0].t().contiguous().to(dt),
+                    self.output_conv[2].bias.detach().float())
+            self._taps = ([_Taps(layer, dt) for layer in self.layers], head)
+            self._taps_key = key
+        return self._taps
+
+    @staticmethod
+    def _mm(acc, a, w):
+        """acc += a @ w with fp32 accumulation/output; a, w in the compute dtype."""
+        if a.dtype == torch.float32:
+            return acc.addmm_(a, w)
+        return acc.add_(torch.mm(a, w).float()) if acc is not None else torch.mm(a, w).float()
+
+    @staticmethod
+    def _gate(y):
+        d = y.shape[1] // 2
+        return torch.tanh(y[:, :d]) * torch.sigmoid(y[:, d:])
+
     @torch.no_grad()
     def generate(self, x_start, label, shape=(3, 3), batch_size=64, generator=None, return_probs=False,
                  uniforms=None):
-        """models.py:176-198: one full forward per grid cell, cell (i,j) drawn from
-        softmax(logits[:, :, i, j]).  `x_start` is accepted and ignored, as in the reference."""
-        param = next(self.parameters())
-        x = torch.zeros((batch_size, *shape), dtype=torch.int64, device=param.device)
+        """Sample a grid of indices, cell by cell in raster order (models.py:176-198).
+        `x_start` is accepted and ignored, as in the reference.  Cell (i,j) is drawn from
+        softmax(logits[:, :, i, j]) with torch.multinomial (optionally `generator`) or, when
+        `uniforms` [B, H*W] is given, by inverse CDF."""
+        H, W = shape
+        layers, (wo1, bo1, wo2, bo2) = self._prepared()
+        dt = self.compute_dtype
+        dev = self.embedding.weight.device
+        B = batch_size
+        L = len(layers)
+        emb = self.embedding.weight.detach()
+        label = label.reshape(-1).to(torch.int64)
+        cond = [t.cond[label] for t in layers]                         # [B, 2d] per layer
+        x = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
+        # XV[l][i][j]: input of layer l's vertical stack at cell (i,j), [B, d] in the compute dtype
+        XV = [[[None] * W for _ in range(H)] for _ in range(L + 1)]
         probs_all = []
-        for i in range(shape[0]):
-            for j in range(shape[1]):
-                logits = self.forward(x, label)
-                probs = F.softmax(logits[:, :, i, j], -1)
+
+        def lin(bias, pairs, n_out):
+            """bias + sum_k a_k @ w_k, fp32 [B, n_out]"""
+            acc = bias.unsqueeze(0).expand(B, n_out).contiguous()
+            for a, w in pairs:
+                if a.dtype == torch.float32:
+                    acc.addmm_(a, w)
+                else:
+                    acc.add_(torch.mm(a, w))
+            return acc
+
+        for i in range(H):
+            # ---- vertical stack of row i, all layers (sees rows < i only) + projection to the horizontal stack
+            v2h = [[None] * W for _ in range(L)]
+            for l, t in enumerate(layers):
+                for j in range(W):
+                    pairs = []
+                    for (da, db), w in t.vert.items():
+                        r, c = i + da, j + db
+                        if 0 <= r < H and 0 <= c < W and XV[l][r][c] is not None:
+                            pairs.append((XV[l][r][c], w))
+                    hv = lin(t.vert_bias, pairs, t.vert_bias.numel())
+                    XV[l + 1][i][j] = self._gate(hv + cond[l]).to(dt)
+                    v2h[l][j] = lin(t.v2h_bias, [(hv.to(dt), t.v2h)], t.v2h_bias.numel())
+            # ---- the cells of row i, left to right
+            XH_prev = None                                           # layer inputs of the cell to the left
+            for j in range(W):
+                XH = [None] * (L + 1)
+                for l, t in enumerate(layers):
+                    pairs = []
+                    for db, w in t.horiz.items():
+                        c = j + db
+                        if c < 0:
+                            continue
+                        if l == 0:
+                            src = XV[0][i][c]                         # embeddings of the sampled cells of this row
+                        else:
+                            src = XH[l] if c == j else (XH_prev[l] if c == j - 1 else None)
+                        if src is not None:
+                            pairs.append((src, w))
+                    hh = lin(t.horiz_bias, pairs, t.horiz_bias.numel())
+                    out = self._gate(v2h[l][j] + hh + cond[l]).to(dt)
+                    nxt = lin(t.resid_bias, [(out, t.resid)], t.resid_bias.numel())
+                    if t.residual:
+                        nxt = nxt + XH[l].float()
+                    XH[l + 1] = nxt.to(dt)
+                hid = torch.relu_(lin(bo1, [(XH[L], wo1)], bo1.numel())).to(dt)
+                logits = lin(bo2, [(hid, wo2)], bo2.numel())
+                probs = F.softmax(logits, -1)
                 probs = probs / probs.sum(dim=1, keepdim=True)
                 if return_probs:
                     probs_all.append(probs)
                 if uniforms is not None:
-                    x[:, i, j] = sample_rows(probs, uniforms[:, i * shape[1] + j])
+                    x[:, i, j] = sample_rows(probs, uniforms[:, i * W + j].contiguous())
                 else:
                     x[:, i, j] = probs.multinomial(1, generator=generator).squeeze(1)
+                XV[0][i][j] = emb[x[:, i, j]].to(dt)                  # this cell is now an input of later ones
+                XH_prev = XH
         if return_probs:
             return x, torch.stack(probs_all, 1)
         return x
+
+    @torch.no_grad()
+    def generate_full(self, label, shape=(3, 3), batch_size=64, forced=None):
+        """The reference's literal procedure (one full forward per cell), with the samples
+        replaced by `forced` indices: returns the per-cell distributions [B, H*W, classes].
+        Used to check generate() against."""
+        x = torch.zeros((batch_size, *shape), dtype=torch.int64, device=self.embedding.weight.device)
+        out = []
+        for i in range(shape[0]):
+            for j in range(shape[1]):
+                probs = F.softmax(self.forward(x, label)[:, :, i, j], -1)
+                out.append(probs / probs.sum(dim=1, keepdim=True))
+                x[:, i, j] = forced[:, i, j]
+        return torch.stack(out, 1)
