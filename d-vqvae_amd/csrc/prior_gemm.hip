@@ -1,0 +1,365 @@
+// Matrix products of the GatedPixelCNN prior with fused gate / residual epilogues (gfx950).
+//
+// The prior (DVQ-VAE/network/pixelcnn/models.py:65-88, 161-198), evaluated cell by cell,
+// is a chain of [batch, K] x [K, N] products: masked-convolution taps, 1x1 projections and
+// the output head.  They run here in the transposed domain, out^T = W * x^T, on bf16 MFMA
+// 32x32x16 with fp32 accumulation: the WEIGHTS are the A operand (rows = output feature)
+// and the ACTIVATIONS the B operand (columns = sample).  The accumulator then holds a
+// sample on the lane and 16 output features in the registers, which is exactly the
+// B-operand layout of the next product of the chain (accumulator-as-operand), so
+// activations are stored between kernels as "packed" 1-KiB units
+//     unit(fb, sb, s) = 64 lanes x 8 bf16:  lane (c,h), j -> feature 32fb + 16s + 8(j>>2) + 4h + (j&3)
+//                                                          of sample 32sb + c
+// written and read as contiguous 16 B per lane (fully coalesced), never re-laid.
+// Weights are packed once per checkpoint into A-fragment units with the same k order.
+//
+// One product sums over several (activation, weight) pairs ("taps": kernel positions of a
+// masked convolution, or the horizontal stack's inputs) before its epilogue:
+//   PACK  y = acc + bias (+ residual) (relu)          -> packed bf16
+//   GATE  tanh(y[n]) * sigmoid(y[n+N/2]), y = acc + bias + class_embedding[label]
+//                                                      -> packed bf16 (N/2 features),
+//         optionally also y without the class term     -> packed bf16 (N features)
+//   ROWS  y = acc + bias                               -> fp32 [M, N] row-major (logits)
+//
+// Tiling: a wave owns NO=4 output-feature tiles x NS=2 sample tiles (128 x 64); the four
+// waves of a workgroup share the weight tiles, staged through LDS in 32-KiB double-buffered
+// stages by direct global->LDS loads; activation fragments go straight from L2 to
+// registers (each feeds four MFMAs).
+#include "common.h"
+
+namespace dvq {
+
+constexpr int kPgWaves = 4;
+constexpr int kPgNO = 4;
+constexpr int kPgNS = 2;
+constexpr int kPgStageKB = 4;   // k-blocks (of 32 features) per LDS stage
+constexpr int kPgMaxTaps = 10;
+
+struct PgTapDev {
+    const char* x;   // packed activations
+    const char* w;   // packed weights of this tap
+    int kb;          // k-blocks of 32 features
+};
+struct PgJobDev {
+    PgTapDev taps[kPgMaxTaps];
+    int n_taps;
+    const float* bias;
+    const float* cond;
+    const int64_t* label;
+    const char* resid;
+    char* out_packed;
+    char* out_pre;
+    float* out_rows;
+};
+struct PgJobs {
+    PgJobDev j[3];
+};
+
+__device__ __forceinline__ void pg_glds16(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16_bits(v[j]);
+    uint4 o;
+    o.x = e[0] | (e[1] << 16); o.y = e[2] | (e[3] << 16); o.z = e[4] | (e[5] << 16); o.w = e[6] | (e[7] << 16);
+    return o;
+}
+
+enum { PG_PACK = 0, PG_GATE = 1, PG_ROWS = 2 };
+
+// grid: x = output-feature group (128 features; for GATE 64 + the matching 64 of the upper half),
+//       y = group of 4*NS sample tiles, z = job
+template <int EPI>
+__global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PgJobDev& job = jobs.j[blockIdx.z];
+    constexpr int NO = kPgNO, NS = kPgNS;
+    constexpr int STAGE_BYTES = NO * kPgStageKB * 2 * 1024;   // 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int SB = (M + 31) / 32;
+    const int n_ob = N / 32;
+
+    int ob[NO];
+    if (EPI == PG_GATE) {
+        const int half = n_ob / 2;
+        ob[0] = 2 * blockIdx.x; ob[1] = 2 * blockIdx.x + 1; ob[2] = half + 2 * blockIdx.x; ob[3] = half + 2 * blockIdx.x + 1;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NO; ++t) ob[t] = NO * blockIdx.x + t;
+    }
+    int sb[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        sb[s] = (blockIdx.y * kPgWaves + wave) * NS + s;
+        if (sb[s] >= SB) sb[s] = SB - 1;   // surplus tiles recompute the last one; their stores are skipped
+    }
+    const bool live0 = ((blockIdx.y * kPgWaves + wave) * NS + 0) < SB;
+    const bool live1 = ((blockIdx.y * kPgWaves + wave) * NS + 1) < SB;
+
+    f32x16 acc[NO][NS];
+#pragma unroll
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][s][i] = 0.f;
+
+    // total stages over all taps
+    int total_stages = 0;
+    for (int t = 0; t < job.n_taps; ++t) total_stages += (job.taps[t].kb + kPgStageKB - 1) / kPgStageKB;
+
+    // issue the direct-to-LDS loads of one stage: for each of the NO feature tiles, `nkb` k-blocks
+    // (2 units each) contiguous in the packed weight.  64 units max -> 16 per wave.
+    auto issue = [&](int tap, int kb0, int nkb, int buf) {
+        const char* w = job.taps[tap].w;
+        const int KB = job.taps[tap].kb;
+        char* dst = smem + buf * STAGE_BYTES;
+        const int units = NO * nkb * 2;
+        for (int u = wave; u < units; u += kPgWaves) {
+            const int t = u / (nkb * 2), q = u % (nkb * 2);
+            const char* src = w + ((int64_t)(ob[t] * KB + kb0) * 2 + q) * 1024 + lane * 16;
+            pg_glds16(src, dst + (t * kPgStageKB * 2 + q) * 1024);
+        }
+    };
+
+    int tap = 0, kb0 = 0;   // stage being issued next
+    auto advance = [&](int& tp, int& k0) {
+        k0 += kPgStageKB;
+        if (k0 >= job.taps[tp].kb) { k0 = 0; ++tp; }
+    };
+    {
+        const int nkb = (job.taps[0].kb - 0) < kPgStageKB ? job.taps[0].kb : kPgStageKB;
+        issue(0, 0, nkb, 0);
+        advance(tap, kb0);
+    }
+    int ctap = 0, ckb0 = 0;  // stage being computed
+    __syncthreads();
+    for (int st = 0; st < total_stages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < total_stages) {
+            const int rem = job.taps[tap].kb - kb0;
+            issue(tap, kb0, rem < kPgStageKB ? rem : kPgStageKB, buf ^ 1);
+            advance(tap, kb0);
+        }
+        {
+            const int rem = job.taps[ctap].kb - ckb0;
+            const int nkb = rem < kPgStageKB ? rem : kPgStageKB;
+            const char* xb = job.taps[ctap].x;
+            const char* wl = smem + buf * STAGE_BYTES + lane * 16;
+#pragma unroll 2
+            for (int k = 0; k < nkb; ++k) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 xf[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        xf[s] = *reinterpret_cast<const bf16x8*>(xb + (((int64_t)(ckb0 + k) * SB + sb[s]) * 2 + s2) * 1024 + lane * 16);
+#pragma unroll
+                    for (int t = 0; t < NO; ++t) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + (t * kPgStageKB * 2 + k * 2 + s2) * 1024);
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) acc[t][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[s], acc[t][s], 0, 0, 0);
+                    }
+                }
+            }
+            advance(ctap, ckb0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  register i of a tile <-> feature 32*ob + (i&3) + 8*(i>>2) + 4h, lane c <-> sample 32*sb + c
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool live = s == 0 ? live0 : live1;
+        if (!live) continue;
+        int m = sb[s] * 32 + c;
+        const bool mvalid = m < M;
+        if (!mvalid) m = M - 1;
+        if (EPI == PG_GATE) {
+            const float* crow = job.cond + job.label[m] * N;
+#pragma unroll
+            for (int t = 0; t < NO / 2; ++t) {
+                float g[16], pre_lo[16], pre_hi[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int nlo = 32 * ob[t] + 8 * q4 + 4 * h, nhi = 32 * ob[t + NO / 2] + 8 * q4 + 4 * h;
+                    const f32x4 blo = *reinterpret_cast<const f32x4*>(job.bias + nlo);
+                    const f32x4 bhi = *reinterpret_cast<const f32x4*>(job.bias + nhi);
+                    const f32x4 clo = *reinterpret_cast<const f32x4*>(crow + nlo);
+                    const f32x4 chi = *reinterpret_cast<const f32x4*>(crow + nhi);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 4 * q4 + q;
+                        pre_lo[i] = acc[t][s][i] + blo[q];
+                        pre_hi[i] = acc[t + NO / 2][s][i] + bhi[q];
+                        g[i] = fast_tanh(pre_lo[i] + clo[q]) * fast_sigmoid(pre_hi[i] + chi[q]);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    *reinterpret_cast<uint4*>(job.out_packed + (((int64_t)ob[t] * SB + sb[s]) * 2 + s2) * 1024 + lane * 16) = pack8(g + 8 * s2);
+                    if (job.out_pre) {
+                        *reinterpret_cast<uint4*>(job.out_pre + (((int64_t)ob[t] * SB + sb[s]) * 2 + s2) * 1024 + lane * 16) = pack8(pre_lo + 8 * s2);
+                        *reinterpret_cast<uint4*>(job.out_pre + (((int64_t)ob[t + NO / 2] * SB + sb[s]) * 2 + s2) * 1024 + lane * 16) = pack8(pre_hi + 8 * s2);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NO; ++t) {
+                float y[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int n0 = 32 * ob[t] + 8 * q4 + 4 * h;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(job.bias + n0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y[4 * q4 + q] = acc[t][s][4 * q4 + q] + b[q];
+                    if (EPI == PG_ROWS) {
+                        if (mvalid) {
+                            f32x4 o; o[0] = y[4 * q4]; o[1] = y[4 * q4 + 1]; o[2] = y[4 * q4 + 2]; o[3] = y[4 * q4 + 3];
+                            *reinterpret_cast<f32x4*>(job.out_rows + (int64_t)m * N + n0) = o;
+                        }
+                    }
+                }
+                if (EPI == PG_PACK) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int64_t off = (((int64_t)ob[t] * SB + sb[s]) * 2 + s2) * 1024 + lane * 16;
+                        if (job.resid) {
+                            const u16x8 rr = *reinterpret_cast<const u16x8*>(job.resid + off);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) y[8 * s2 + j] += bf16_bits_to_f32(rr[j]);
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) y[8 * s2 + j] = y[8 * s2 + j] > 0.f ? y[8 * s2 + j] : 0.f;
+                        }
+                        *reinterpret_cast<uint4*>(job.out_packed + off) = pack8(y + 8 * s2);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// W [N, K] (fp32, element (n,k) at W[n*ldn + k*ldk]) -> packed A-fragment units
+//   unit (ob, fb, s): lane (r,h), j -> W[32ob + r][32fb + 16s + 8(j>>2) + 4h + (j&3)]
+__global__ void prior_pack_weight_kernel(const float* __restrict__ W, int64_t ldn, int64_t ldk, int N, int K, uint4* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KB = K / 32;
+    const int64_t total = (int64_t)(N / 32) * KB * 2 * 64;
+    if (t >= total) return;
+    const int l = (int)(t & 63);
+    const int64_t unit = t >> 6;
+    const int s = (int)(unit & 1);
+    const int fb = (int)((unit >> 1) % KB);
+    const int ob = (int)((unit >> 1) / KB);
+    const int r = l & 31, h = l >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)(32 * ob + r) * ldn + (int64_t)(32 * fb + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * ldk];
+    out[t] = pack8(v);
+}
+
+// packed[fb][sb][s][lane] <- table[idx[m]][feature]   (embedding rows of sampled indices)
+__global__ void prior_embed_kernel(const int64_t* __restrict__ idx, int64_t idx_stride, const float* __restrict__ table, int V, int M, int d,
+                                   uint4* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int SB = (M + 31) / 32;
+    const int64_t total = (int64_t)(d / 32) * SB * 2 * 64;
+    if (t >= total) return;
+    const int l = (int)(t & 63);
+    const int64_t unit = t >> 6;
+    const int s = (int)(unit & 1);
+    const int sbk = (int)((unit >> 1) % SB);
+    const int fb = (int)((unit >> 1) / SB);
+    const int c = l & 31, h = l >> 5;
+    int m = sbk * 32 + c;
+    if (m >= M) m = M - 1;
+    int64_t row = idx[(int64_t)m * idx_stride];
+    if (row < 0) row = 0;
+    if (row >= V) row = V - 1;
+    const float* src = table + row * d + 32 * fb + 16 * s + 4 * h;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[8 * (j >> 2) + (j & 3)];
+    out[t] = pack8(v);
+}
+
+}  // namespace dvq
+
+using namespace dvq;
+
+extern "C" size_t dvq_prior_packed_bytes(int rows, int features) {
+    if (rows < 1 || features < 32 || (features % 32) != 0) return 0;
+    return (size_t)(features / 32) * ((rows + 31) / 32) * 2048;
+}
+
+extern "C" int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K, void* out, void* stream) {
+    if (!W || !out || N < 32 || K < 32 || (N % 32) || (K % 32)) return fail(DVQ_EINVAL, "prior_pack_weight: N and K must be multiples of 32");
+    const int64_t total = (int64_t)(N / 32) * (K / 32) * 2 * 64;
+    hipLaunchKernelGGL(prior_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), W, ldn, ldk, N, K,
+                       reinterpret_cast<uint4*>(out));
+    return check_launch("prior_pack_weight");
+}
+
+extern "C" int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, void* out, void* stream) {
+    if (!idx || !table || !out || M < 1 || d < 32 || (d % 32)) return fail(DVQ_EINVAL, "prior_embed: bad arguments");
+    const int64_t total = (int64_t)(d / 32) * ((M + 31) / 32) * 2 * 64;
+    hipLaunchKernelGGL(prior_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), idx, idx_stride, table, V, M, d,
+                       reinterpret_cast<uint4*>(out));
+    return check_launch("prior_embed");
+}
+
+extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, void* stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > 3) return fail(DVQ_EINVAL, "prior_gemm: 1..3 jobs per launch");
+    if (M < 1 || N < 128 || (N % 128) != 0) return fail(DVQ_EINVAL, "prior_gemm: N must be a multiple of 128 (got %d)", N);
+    if (epilogue == PG_GATE && (N % 256) != 0) return fail(DVQ_EINVAL, "prior_gemm: the gate epilogue needs N %% 256 == 0");
+    PgJobs dev;
+    for (int j = 0; j < n_jobs; ++j) {
+        const DvqPriorJob& s = jobs[j];
+        if (s.n_taps < 1 || s.n_taps > kPgMaxTaps) return fail(DVQ_EINVAL, "prior_gemm: 1..%d taps per job", kPgMaxTaps);
+        PgJobDev& d = dev.j[j];
+        d.n_taps = s.n_taps;
+        for (int t = 0; t < s.n_taps; ++t) {
+            if (!s.taps[t].x || !s.taps[t].w || s.taps[t].k_blocks < 1) return fail(DVQ_EINVAL, "prior_gemm: bad tap %d", t);
+            d.taps[t].x = reinterpret_cast<const char*>(s.taps[t].x);
+            d.taps[t].w = reinterpret_cast<const char*>(s.taps[t].w);
+            d.taps[t].kb = s.taps[t].k_blocks;
+        }
+        if (!s.bias) return fail(DVQ_EINVAL, "prior_gemm: bias is required");
+        d.bias = s.bias; d.cond = s.cond; d.label = s.label;
+        d.resid = reinterpret_cast<const char*>(s.resid);
+        d.out_packed = reinterpret_cast<char*>(s.out_packed);
+        d.out_pre = reinterpret_cast<char*>(s.out_pre);
+        d.out_rows = s.out_rows;
+        if (epilogue == PG_GATE && (!s.cond || !s.label || !s.out_packed)) return fail(DVQ_EINVAL, "prior_gemm: gate needs cond, label, out_packed");
+        if (epilogue == PG_PACK && !s.out_packed) return fail(DVQ_EINVAL, "prior_gemm: out_packed missing");
+        if (epilogue == PG_ROWS && !s.out_rows) return fail(DVQ_EINVAL, "prior_gemm: out_rows missing");
+    }
+    const int SB = (M + 31) / 32;
+    const dim3 grid(N / 128, (SB + kPgWaves * kPgNS - 1) / (kPgWaves * kPgNS), n_jobs);
+    const size_t lds = 2 * (size_t)kPgNO * kPgStageKB * 2 * 1024;
+    hipStream_t st = as_stream(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(prior_gemm_kernel<PG_PACK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(prior_gemm_kernel<PG_GATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(prior_gemm_kernel<PG_ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!ok) return fail(DVQ_ELAUNCH, "prior_gemm: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    if (epilogue == PG_PACK) hipLaunchKernelGGL((prior_gemm_kernel<PG_PACK>), grid, dim3(kPgWaves * 64), lds, st, dev, M, N, relu);
+    else if (epilogue == PG_GATE) hipLaunchKernelGGL((prior_gemm_kernel<PG_GATE>), grid, dim3(kPgWaves * 64), lds, st, dev, M, N, relu);
+    else if (epilogue == PG_ROWS) hipLaunchKernelGGL((prior_gemm_kernel<PG_ROWS>), grid, dim3(kPgWaves * 64), lds, st, dev, M, N, relu);
+    else return fail(DVQ_EINVAL, "prior_gemm: unknown epilogue %d", epilogue);
+    return check_launch("prior_gemm");
+}

@@ -28,6 +28,16 @@ class DvqManoConsts(ctypes.Structure):
                 ("pose_mean", c_void_p), ("parents", c_void_p)]
 
 
+class DvqPriorTap(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("k_blocks", c_int)]
+
+
+class DvqPriorJob(ctypes.Structure):
+    _fields_ = [("taps", DvqPriorTap * 10), ("n_taps", c_int), ("bias", c_void_p), ("cond", c_void_p),
+                ("label", c_void_p), ("resid", c_void_p), ("out_packed", c_void_p), ("out_pre", c_void_p),
+                ("out_rows", c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/dvq_hip.h one to one
 SIGNATURES = {
     "dvq_version": (c_int, []),
@@ -42,6 +52,10 @@ SIGNATURES = {
     "dvq_pointnet_mlp_max": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DvqPointMlp), c_int, c_int, c_void_p, c_void_p]),
     "dvq_fold_bn": (c_int, [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dvq_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "dvq_prior_packed_bytes": (c_size_t, [c_int, c_int]),
+    "dvq_prior_pack_weight": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dvq_prior_gemm": (c_int, [POINTER(DvqPriorJob), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import DVQ_BF16, DVQ_F32, DvqManoConsts, DvqPointMlp
+from ._lib import DVQ_BF16, DVQ_F32, DvqManoConsts, DvqPointMlp, DvqPriorJob
 
 
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
@@ -202,3 +202,60 @@ def mano_lbs(global_orient, hand_pose, transl, consts: DvqManoConsts, n_verts: i
                                       _p(verts), _p(joints), _p(full), _stream(hand_pose))
     _lib.check(rc, "dvq_mano_lbs")
     return verts, joints, full
+
+
+# ------------------------------------------------------------------------ prior
+PRIOR_PACK, PRIOR_GATE, PRIOR_ROWS = 0, 1, 2
+
+
+def prior_packed_empty(rows: int, features: int, device, zero: bool = False) -> torch.Tensor:
+    """Buffer for `rows` x `features` activations in the packed bf16 layout of the prior kernels."""
+    n = _lib.load().dvq_prior_packed_bytes(rows, features)
+    if n == 0:
+        raise RuntimeError("prior_packed_empty: features must be a positive multiple of 32")
+    return (torch.zeros if zero else torch.empty)(n, dtype=torch.uint8, device=device)
+
+
+def prior_pack_weight(W: torch.Tensor) -> torch.Tensor:
+    """W [N, K] fp32 (any strides, e.g. one kernel tap of a conv weight) -> packed bf16."""
+    if not W.is_cuda or W.dtype != torch.float32 or W.dim() != 2:
+        raise RuntimeError("prior_pack_weight: a 2-D float32 HIP tensor is required")
+    N, K = W.shape
+    out = torch.empty(N * K * 2, dtype=torch.uint8, device=W.device)
+    with torch.cuda.device(W.device):
+        rc = _lib.load().dvq_prior_pack_weight(_p(W), W.stride(0), W.stride(1), N, K, _p(out), _stream(W))
+    _lib.check(rc, "dvq_prior_pack_weight")
+    return out
+
+
+def prior_embed(idx: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out (packed) <- table[idx]; idx is a 1-D int64 view (may be strided)."""
+    _need_gpu(table, out)
+    M = idx.shape[0]
+    V, d = table.shape
+    with torch.cuda.device(table.device):
+        rc = _lib.load().dvq_prior_embed(_p(idx), idx.stride(0), _p(table), V, M, d, _p(out), _stream(table))
+    _lib.check(rc, "dvq_prior_embed")
+    return out
+
+
+def prior_job(taps, bias, cond=None, label=None, resid=None, out_packed=None, out_pre=None, out_rows=None) -> DvqPriorJob:
+    """taps: list of (packed activations, packed weights, k_blocks)."""
+    j = DvqPriorJob()
+    if not 1 <= len(taps) <= 10:
+        raise RuntimeError("prior_job: 1..10 taps")
+    for t, (x, w, kb) in enumerate(taps):
+        j.taps[t].x, j.taps[t].w, j.taps[t].k_blocks = x.data_ptr(), w.data_ptr(), kb
+    j.n_taps = len(taps)
+    j.bias = bias.data_ptr()
+    for name, t in (("cond", cond), ("label", label), ("resid", resid), ("out_packed", out_packed), ("out_pre", out_pre),
+                    ("out_rows", out_rows)):
+        setattr(j, name, t.data_ptr() if t is not None else None)
+    return j
+
+
+def prior_gemm(jobs, M: int, N: int, epilogue: int, relu: bool, ref: torch.Tensor) -> None:
+    arr = (DvqPriorJob * len(jobs))(*jobs)
+    with torch.cuda.device(ref.device), _timed("prior_gemm", (M, N, len(jobs)), ref):
+        rc = _lib.load().dvq_prior_gemm(arr, len(jobs), M, N, epilogue, int(relu), _stream(ref))
+    _lib.check(rc, "dvq_prior_gemm")

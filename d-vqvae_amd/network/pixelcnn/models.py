@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from dvq_hip import ops
 from dvq_hip.rng import sample_rows
 
 
@@ -104,6 +105,28 @@ class _Taps:
         self.residual = layer.residual
 
 
+class _PackedTaps:
+    """The same per-tap matrices as _Taps, packed for the HIP products (dvq_prior_gemm):
+    bf16 A-operand fragment order, biases and class embeddings in fp32."""
+
+    def __init__(self, layer: GatedMaskedConv2d):
+        k = layer.kernel
+        wv = layer.vert_stack.weight.detach().float()
+        wh = layer.horiz_stack.weight.detach().float()
+        rows = k // 2 + 1
+        live = range(rows - 1) if layer.mask_type == 'A' else range(rows)
+        self.vert = {(a - k // 2, b - k // 2): ops.prior_pack_weight(wv[:, :, a, b]) for a in live for b in range(k)}
+        self.horiz = {b - k // 2: ops.prior_pack_weight(wh[:, :, 0, b]) for b in live}
+        self.v2h = ops.prior_pack_weight(layer.vert_to_horiz.weight.detach().float()[:, :, 0, 0])
+        self.resid = ops.prior_pack_weight(layer.horiz_resid.weight.detach().float()[:, :, 0, 0])
+        self.vert_bias = layer.vert_stack.bias.detach().float().contiguous()
+        # the horizontal stack adds the projected vertical features before its gate (models.py:79-81)
+        self.horiz_bias = (layer.horiz_stack.bias.detach().float() + layer.vert_to_horiz.bias.detach().float()).contiguous()
+        self.resid_bias = layer.horiz_resid.bias.detach().float().contiguous()
+        self.cond = layer.class_cond_embedding.weight.detach().float().contiguous()
+        self.residual = layer.residual
+
+
 class GatedPixelCNN(nn.Module):
     def __init__(self, input_dim=256, dim=128, n_layers=15, n_classes=128):
         super().__init__()
@@ -117,6 +140,9 @@ class GatedPixelCNN(nn.Module):
         self.compute_dtype = torch.float32     # operand precision of the matrix products in generate()
         self._taps_key = None
         self._taps = None
+        self._packed_key = None
+        self._packed = None
+        self._bufs = {}
 
     def forward(self, x, label):
         shp = x.size() + (-1,)
@@ -139,6 +165,96 @@ class GatedPixelCNN(nn.Module):
             self._taps_key = key
         return self._taps
 
+    def _prepared_hip(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key != self._packed_key:
+            head = (ops.prior_pack_weight(self.output_conv[0].weight.detach().float()[:, :, 0, 0]),
+                    self.output_conv[0].bias.detach().float().contiguous(),
+                    ops.prior_pack_weight(self.output_conv[2].weight.detach().float()[:, :, 0, 0]),
+                    self.output_conv[2].bias.detach().float().contiguous())
+            self._packed = ([_PackedTaps(layer) for layer in self.layers], head)
+            self._packed_key = key
+            self._bufs = {}
+        return self._packed
+
+    def _act_buffers(self, B, H, W, dev):
+        """Packed activation buffers for a batch of B grids, allocated once per (B, H, W)."""
+        key = (B, H, W, str(dev))
+        if key not in self._bufs:
+            L, d = len(self.layers), self.dim
+            e = lambda f, zero=False: ops.prior_packed_empty(B, f, dev, zero)
+            self._bufs = {key: dict(
+                XV=[[[e(d) for _ in range(W)] for _ in range(H)] for _ in range(L + 1)],
+                HV=[[e(2 * d) for _ in range(W)] for _ in range(L)],
+                XH=[[e(d) for _ in range(L + 1)] for _ in range(2)],
+                OUT=e(d), HID=e(self.output_conv[0].out_channels), Z=e(d, True),
+                logits=torch.empty(B, self.output_conv[2].out_channels, dtype=torch.float32, device=dev))}
+        return self._bufs[key]
+
+    @torch.no_grad()
+    def _generate_hip(self, label, shape, B, generator, return_probs, uniforms):
+        """generate() on the fused bf16 kernels: per grid row one launch per layer for the
+        vertical stack (3 cells at once, gate fused), per cell two launches per layer for the
+        horizontal stack (taps + projected vertical features + gate; residual 1x1), two for
+        the head."""
+        H, W = shape
+        layers, (wo1, bo1, wo2, bo2) = self._prepared_hip()
+        dev = self.embedding.weight.device
+        bufs = self._act_buffers(B, H, W, dev)
+        XV, HV, XHb, OUT, HID, Z, logits = (bufs[k] for k in ("XV", "HV", "XH", "OUT", "HID", "Z", "logits"))
+        L, d = len(layers), self.dim
+        kb = d // 32
+        emb = self.embedding.weight.detach().float().contiguous()
+        label = label.reshape(-1).to(torch.int64).contiguous()
+        x = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
+        n_out = logits.shape[1]
+        probs_all = []
+        for i in range(H):
+            for l, t in enumerate(layers):
+                jobs = []
+                for j in range(W):
+                    taps = [(XV[l][i + da][j + db], w, kb) for (da, db), w in t.vert.items()
+                            if 0 <= i + da < H and 0 <= j + db < W and (l > 0 or i + da < i)]
+                    if not taps:                                     # nothing above this row: bias only
+                        taps = [(Z, next(iter(t.vert.values())), kb)]
+                    jobs.append(ops.prior_job(taps, t.vert_bias, cond=t.cond, label=label, out_packed=XV[l + 1][i][j],
+                                              out_pre=HV[l][j]))
+                ops.prior_gemm(jobs, B, 2 * d, ops.PRIOR_GATE, False, emb)
+            for j in range(W):
+                XH, XHp = XHb[j & 1], XHb[(j & 1) ^ 1]
+                for l, t in enumerate(layers):
+                    taps = []
+                    for db, w in t.horiz.items():
+                        c = j + db
+                        if c < 0:
+                            continue
+                        if l == 0:
+                            taps.append((XV[0][i][c], w, kb))
+                        elif c == j:
+                            taps.append((XH[l], w, kb))
+                        elif c == j - 1:
+                            taps.append((XHp[l], w, kb))
+                    taps.append((HV[l][j], t.v2h, 2 * kb))
+                    ops.prior_gemm([ops.prior_job(taps, t.horiz_bias, cond=t.cond, label=label, out_packed=OUT)],
+                                   B, 2 * d, ops.PRIOR_GATE, False, emb)
+                    ops.prior_gemm([ops.prior_job([(OUT, t.resid, kb)], t.resid_bias, resid=XH[l] if t.residual else None,
+                                                  out_packed=XH[l + 1])], B, d, ops.PRIOR_PACK, False, emb)
+                ops.prior_gemm([ops.prior_job([(XH[L], wo1, kb)], bo1, out_packed=HID)], B, bo1.numel(), ops.PRIOR_PACK, True, emb)
+                ops.prior_gemm([ops.prior_job([(HID, wo2, bo1.numel() // 32)], bo2, out_rows=logits)], B, n_out, ops.PRIOR_ROWS,
+                               False, emb)
+                probs = F.softmax(logits, -1)
+                probs = probs / probs.sum(dim=1, keepdim=True)
+                if return_probs:
+                    probs_all.append(probs)
+                if uniforms is not None:
+                    x[:, i, j] = sample_rows(probs, uniforms[:, i * W + j].contiguous())
+                else:
+                    x[:, i, j] = probs.multinomial(1, generator=generator).squeeze(1)
+                ops.prior_embed(x[:, i, j], emb, XV[0][i][j])
+        if return_probs:
+            return x, torch.stack(probs_all, 1)
+        return x
+
     @staticmethod
     def _mm(acc, a, w):
         """acc += a @ w with fp32 accumulation/output; a, w in the compute dtype."""
@@ -159,6 +275,8 @@ class GatedPixelCNN(nn.Module):
         softmax(logits[:, :, i, j]) with torch.multinomial (optionally `generator`) or, when
         `uniforms` [B, H*W] is given, by inverse CDF."""
         H, W = shape
+        if self.compute_dtype == torch.bfloat16:
+            return self._generate_hip(label, shape, batch_size, generator, return_probs, uniforms)
         layers, (wo1, bo1, wo2, bo2) = self._prepared()
         dt = self.compute_dtype
         dev = self.embedding.weight.device

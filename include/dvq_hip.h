@@ -138,6 +138,51 @@ int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float
                  const DvqManoConsts* m, float* verts_out, float* joints_out, float* full_pose_out,
                  void* stream);
 
+/* ------------------------------------------------------------ prior (PixelCNN)
+ * Matrix products of the GatedPixelCNN prior evaluated cell by cell (reference:
+ * DVQ-VAE/network/pixelcnn/models.py:65-88 gated layer, :161-174 forward, :176-198 generate),
+ * bf16 operands / fp32 accumulation, with the gate and residual fused.  Activations are kept
+ * between calls in "packed" bf16 form (dvq_prior_packed_bytes(rows, features) bytes; layout
+ * in csrc/prior_gemm.hip), weights are packed once by dvq_prior_pack_weight.
+ *
+ * dvq_prior_gemm runs 1..3 independent jobs of the same shape in one launch.  A job computes
+ *   y[m, :] = bias + sum over taps  W_tap * x_tap[m, :]        (N outputs, M rows)
+ * and finishes with one of
+ *   DVQ_PRIOR_PACK  out_packed = y (+ resid) (relu if `relu`)                      [N features]
+ *   DVQ_PRIOR_GATE  out_packed = tanh(u[:N/2]) * sigmoid(u[N/2:]), u = y + cond[label[m]]
+ *                   (models.py:25-27, 70-75); out_pre (optional) = y              [N/2], [N]
+ *   DVQ_PRIOR_ROWS  out_rows[m, n] = y   (fp32 row-major, the logits)
+ */
+#define DVQ_PRIOR_PACK 0
+#define DVQ_PRIOR_GATE 1
+#define DVQ_PRIOR_ROWS 2
+#define DVQ_PRIOR_MAX_TAPS 10
+
+typedef struct {
+    const void* x;      /* packed activations, 32*k_blocks features */
+    const void* w;      /* packed weights [N, 32*k_blocks]           */
+    int k_blocks;
+} DvqPriorTap;
+
+typedef struct {
+    DvqPriorTap taps[DVQ_PRIOR_MAX_TAPS];
+    int n_taps;
+    const float* bias;      /* [N]                                         */
+    const float* cond;      /* [n_classes, N] class embedding (GATE)       */
+    const int64_t* label;   /* [M] class of each row (GATE)                */
+    const void* resid;      /* packed [N features] added before relu (PACK) or NULL */
+    void* out_packed;
+    void* out_pre;
+    float* out_rows;
+} DvqPriorJob;
+
+size_t dvq_prior_packed_bytes(int rows, int features);
+/* W element (n,k) at W[n*ldn + k*ldk] (a kernel tap of a conv weight is a strided view) */
+int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K, void* out, void* stream);
+/* out(packed)[m] = table[idx[m*idx_stride]]: embedding rows of sampled indices, d features */
+int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, void* out, void* stream);
+int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,32 @@ def test_prior_incremental_sampling_equals_full_forwards():
     assert (probs[:3].cpu().view(3, 3, 3, -1) - p_cpu).abs().max().item() <= 2e-4
 
 
+def test_prior_bf16_kernels_vs_fp32():
+    """The fused bf16 prior kernels against the fp32 evaluation on the same forced grid.
+    Stated tolerance: per-cell class probabilities within 5e-2 absolute (bf16 operands through
+    15 gated layers), and >= 85 % of the sampled indices equal for identical uniforms."""
+    model, _ = build()
+    prior = model.GatedPixelCNN
+    B = 100                                    # not a multiple of the 32-row tile
+    lab = torch.randint(0, 128, (B,), device=DEV, generator=torch.Generator(DEV).manual_seed(2))
+    from dvq_hip import rng
+    u = rng.uniforms(torch.arange(B, device=DEV), 9, seed=9)
+    x32, p32 = prior.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u, return_probs=True)
+    prior.compute_dtype = torch.bfloat16
+    x16, p16 = prior.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u, return_probs=True)
+    # the sampled grids feed back into later cells, so compare distributions on a common grid: re-evaluate
+    # the fp32 distributions on the grid the bf16 run produced
+    prior.compute_dtype = torch.float32
+    ref = prior.generate_full(lab, shape=(3, 3), batch_size=B, forced=x16)
+    err = (p16 - ref).abs().max().item()
+    agree = (x16 == x32).float().mean().item()
+    print(f"bf16 prior: max |dp| {err:.3e}, sampled-index agreement {agree:.3f}")
+    assert err <= 5e-2 and agree >= 0.85 and int(x16.max()) < 128
+    prior.compute_dtype = torch.bfloat16
+    x16b = prior.generate(None, lab[32:77].contiguous(), shape=(3, 3), batch_size=45, uniforms=u[32:77].contiguous())
+    assert torch.equal(x16b, x16[32:77])       # independent of batch composition
+
+
 def test_gen_bf16_stated_tolerance():
     """bf16 encoders: vertices within 2 mm of the fp32 path on a ~0.2 m hand (stated
     tolerance), object-code agreement reported."""
