@@ -244,6 +244,158 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_reg_kernel(
     }
 }
 
+
+// ------------------------------------------ bf16 fast path: argmax of <z,E_k> - |E_k|^2/2
+// |z|^2 is the same for every code of a row, so the nearest code is the one maximising
+// <z,E_k> - |E_k|^2/2.  The accumulator of each 32x32 tile is INITIALISED with -|E_k|^2/2
+// and the MFMA chain adds the dot product, so the per-element work after the matrix cores is
+// three VALU operations (compare, select index, max) -- the matrix pipe stays the bottleneck.
+// No term is rounded at the magnitude of |z|^2, so this is at least as accurate as the
+// reference's formula; rows where the two can disagree are near-ties of the reference's
+// own rounding.  A tile in the packed codebook is U units of E followed by one unit whose
+// first 128 bytes hold -|E_k|^2/2 of its 32 codes (-inf for padding codes): the whole stage
+// is one linear global->LDS stream.
+__device__ __forceinline__ void vq_glds16(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ void vq_pack_bf16x_kernel(const unsigned short* __restrict__ E, int K, int D, int Kpad, uint4* __restrict__ packed) {
+    // group of 32 codes = 2 tiles of 16 codes x (D/32) k-steps of 32 dims, then one unit of -|E|^2/2.
+    // E unit (hh, s): lane (c = l&15, q = l>>4) holds E[32g + 16hh + c][32s + 8q .. +8]  (16x16x32 A fragment)
+    const int S = D / 32;
+    const int UG = 2 * S + 1;
+    const int64_t nchunks = (int64_t)(Kpad / 32) * UG * 64;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const int l = (int)(t & 63);
+    const int64_t unit = t >> 6;
+    const int u = (int)(unit % UG);
+    const int g = (int)(unit / UG);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (u < 2 * S) {
+        const int hh = u / S, ss = u % S;
+        const int code = g * 32 + 16 * hh + (l & 15);
+        if (code < K) v = *reinterpret_cast<const uint4*>(E + (int64_t)code * D + 32 * ss + 8 * (l >> 4));
+    } else if (l < 8) {  // lane l: codes 4l .. 4l+3 of the group
+        float o[4];
+        for (int q = 0; q < 4; ++q) {
+            const int code = g * 32 + 4 * l + q;
+            float acc = __builtin_inff();
+            if (code < K) {
+                acc = 0.f;
+                const unsigned short* row = E + (int64_t)code * D;
+                for (int d = 0; d < D; ++d) { const float x = bf16_bits_to_f32(row[d]); acc = __builtin_fmaf(x, x, acc); }
+            }
+            o[q] = -0.5f * acc;
+        }
+        v.x = __builtin_bit_cast(unsigned, o[0]); v.y = __builtin_bit_cast(unsigned, o[1]);
+        v.z = __builtin_bit_cast(unsigned, o[2]); v.w = __builtin_bit_cast(unsigned, o[3]);
+    }
+    packed[t] = v;
+}
+
+// One wave owns NB tiles of 16 latents (MFMA 16x16x32: columns = latents, rows = codes); lane
+// (c = lane&15, q = lane>>4) holds latent c's dims 32s+8q..+8 for every k-step s -- 64 contiguous
+// bytes per latent row and instruction when loading z -- and, in the accumulator, codes 4q..4q+3
+// of the 16-code tile.
+template <int D, int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_kernel(
+    const unsigned short* __restrict__ z, const char* __restrict__ packed, int64_t n, int n_tiles, int TS,
+    int64_t* __restrict__ idx_out) {
+    constexpr int S = D / 32;
+    constexpr int TILE_BYTES = (2 * S + 1) * 1024;   // a group of 32 codes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n_stages = (n_tiles + TS - 1) / TS;
+    const int stage_bytes = TS * TILE_BYTES;
+    const int n_buf = n_stages > 1 ? 2 : 1;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c = lane & 15;
+    const int q = lane >> 4;
+    constexpr int LAT_PER_BLOCK = WAVES * NB * 16;
+    const int64_t n_groups = (n + LAT_PER_BLOCK - 1) / LAT_PER_BLOCK;
+
+    auto issue_stage = [&](int st, int buf) {
+        const int t_first = st * TS;
+        const int t_count = (n_tiles - t_first) < TS ? (n_tiles - t_first) : TS;
+        const int units = t_count * (2 * S + 1);
+        const char* src = packed + (int64_t)t_first * TILE_BYTES;
+        char* dst = smem + buf * stage_bytes;
+        for (int u = wave; u < units; u += WAVES) vq_glds16(src + (int64_t)u * 1024 + lane * 16, dst + u * 1024);
+    };
+
+    bool resident = false;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t lat0 = grp * LAT_PER_BLOCK + (int64_t)wave * NB * 16;
+        if (!resident) issue_stage(0, 0);   // lands while the latent rows are fetched
+        bf16x8 zb[NB][S];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            int64_t row = lat0 + nb * 16 + c;
+            if (row >= n) row = n - 1;
+            const unsigned short* zr = z + row * D + 8 * q;
+#pragma unroll
+            for (int s = 0; s < S; ++s) zb[nb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(zr + 32 * s));
+        }
+        float best[NB];
+        int bidx[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { best[nb] = -__builtin_inff(); bidx[nb] = 0; }
+        if (!resident) {
+            __syncthreads();
+            resident = (n_stages == 1);
+        }
+        for (int st = 0; st < n_stages; ++st) {
+            const int buf = st & (n_buf - 1);
+            if (st + 1 < n_stages) issue_stage(st + 1, buf ^ 1);
+            const int t_first = st * TS;
+            const int t_count = (n_tiles - t_first) < TS ? (n_tiles - t_first) : TS;
+            const char* eb = smem + buf * stage_bytes;
+            for (int t = 0; t < t_count; ++t) {
+                const char* tb = eb + t * TILE_BYTES;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x4 e = *reinterpret_cast<const f32x4*>(tb + 2 * S * 1024 + (16 * hh + 4 * q) * 4);
+                    f32x4 acc[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = e;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(tb + (hh * S + s) * 1024 + lane * 16);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, zb[nb][s], acc[nb], 0, 0, 0);
+                    }
+                    const int base = (t_first + t) * 32 + 16 * hh + 4 * q;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {   // codes increase with i: '>' keeps the lowest index among equals
+                            const float v = acc[nb][i];
+                            const bool gt = v > best[nb];
+                            bidx[nb] = gt ? base + i : bidx[nb];
+                            best[nb] = gt ? v : best[nb];
+                        }
+                }
+            }
+            if (n_stages > 1) __syncthreads();
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {   // merge the four lanes that share a latent
+                const float ob = __shfl_xor(best[nb], off, 64);
+                const int ok = __shfl_xor(bidx[nb], off, 64);
+                if (ob > best[nb] || (ob == best[nb] && ok < bidx[nb])) { best[nb] = ob; bidx[nb] = ok; }
+            }
+            const int64_t row = lat0 + nb * 16 + c;
+            if (q == 0 && row < n) idx_out[row] = (int64_t)bidx[nb];
+        }
+    }
+}
+
 // --------------------------------------------- generic path: any D % 16 == 0
 // One wave owns 32 latents; z fragments are re-read (L1/L2) for every code tile and the
 // codebook tile is staged through LDS in chunks of CH dims.  Slower; used for the shapes
@@ -340,6 +492,7 @@ __global__ void vq_gather_kernel(const int64_t* __restrict__ idx, const T* __res
 // ------------------------------------------------------------------ host side
 struct VqPlan {
     int Kpad, n_tiles, U, tile_bytes;
+    bool bf16x;   // bf16 fast-path layout: tiles of U+1 units with -|E|^2/2 embedded
     size_t packed_bytes, e2_off, total;
 };
 
@@ -349,7 +502,8 @@ static bool vq_plan(int K, int D, int dtype, VqPlan* p) {
     p->Kpad = round_up(K, 32);
     p->n_tiles = p->Kpad / 32;
     p->U = D / (dtype == DVQ_BF16 ? 16 : 8);
-    p->tile_bytes = p->U * 1024;
+    p->bf16x = dtype == DVQ_BF16 && (D == 64 || D == 128 || D == 256);
+    p->tile_bytes = (p->U + (p->bf16x ? 1 : 0)) * 1024;
     p->packed_bytes = (size_t)p->n_tiles * p->tile_bytes;
     p->e2_off = (p->packed_bytes + 255) / 256 * 256;
     p->total = p->e2_off + (size_t)p->Kpad * 4;
@@ -383,13 +537,35 @@ static int launch_reg(const void* z, const char* ws, const VqPlan& p, int64_t n,
     return check_launch("vq_argmin");
 }
 
+template <int D, int NB, int WAVES>
+static int launch_bf16x(const void* z, const char* ws, const VqPlan& p, int64_t n, int64_t* idx_out, hipStream_t st) {
+    constexpr int TILE_BYTES = (D / 16 + 1) * 1024;
+    int TS = (68 * 1024) / TILE_BYTES;   // 68-KiB stages: 4 groups of 32 codes at D=256
+    if (TS < 1) TS = 1;
+    if (TS > p.n_tiles) TS = p.n_tiles;
+    const int n_stages = (p.n_tiles + TS - 1) / TS;
+    const size_t lds = (size_t)(n_stages > 1 ? 2 : 1) * TS * TILE_BYTES;
+    auto kern = vq_argmax_bf16_kernel<D, NB, WAVES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(DVQ_ELAUNCH, "vq_argmin: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int64_t groups = (n + WAVES * NB * 16 - 1) / (WAVES * NB * 16);
+    const int64_t max_blocks = (lds > 80 * 1024) ? kNumCU : 2 * kNumCU;
+    const int grid = (int)(groups < max_blocks ? groups : max_blocks);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, reinterpret_cast<const unsigned short*>(z), ws, n, p.n_tiles, TS, idx_out);
+    return check_launch("vq_argmin(bf16)");
+}
+
 template <int DT>
 static int launch_search(const void* z, const char* ws, const VqPlan& p, int64_t n, int D, int64_t* idx_out, hipStream_t st) {
     if (n == 0) return DVQ_OK;
     if (DT == DVQ_BF16) {
-        if (D == 256) return launch_reg<DVQ_BF16, 256, 2, 8>(z, ws, p, n, idx_out, st);
-        if (D == 128) return launch_reg<DVQ_BF16, 128, 2, 8>(z, ws, p, n, idx_out, st);
-        if (D == 64) return launch_reg<DVQ_BF16, 64, 2, 8>(z, ws, p, n, idx_out, st);
+        if (D == 256) return launch_bf16x<256, 4, 8>(z, ws, p, n, idx_out, st);
+        if (D == 128) return launch_bf16x<128, 4, 8>(z, ws, p, n, idx_out, st);
+        if (D == 64) return launch_bf16x<64, 4, 8>(z, ws, p, n, idx_out, st);
     } else {
         if (D == 256) return launch_reg<DVQ_F32, 256, 1, 8>(z, ws, p, n, idx_out, st);
         if (D == 128) return launch_reg<DVQ_F32, 128, 2, 8>(z, ws, p, n, idx_out, st);
@@ -420,6 +596,12 @@ static int vq_prepare_impl(const void* E, int K, int D, int dtype, void* ws, con
     const int64_t threads = nchunks > p.Kpad ? nchunks : p.Kpad;
     const int grid = (int)((threads + 255) / 256);
     char* w = reinterpret_cast<char*>(ws);
+    if (p.bf16x) {
+        const int64_t nch = (int64_t)p.n_tiles * (p.U + 1) * 64;   // U = D/16 = 2 tiles x D/32 k-steps
+        hipLaunchKernelGGL(vq_pack_bf16x_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned short*>(E), K, D, p.Kpad, reinterpret_cast<uint4*>(w));
+        return check_launch("vq_prepare");
+    }
     if (dtype == DVQ_BF16)
         hipLaunchKernelGGL((vq_pack_kernel<DVQ_BF16>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(E), K, D,
                            p.Kpad, reinterpret_cast<uint4*>(w), reinterpret_cast<float*>(w + p.e2_off));
