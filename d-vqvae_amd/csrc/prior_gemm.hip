@@ -21,18 +21,16 @@
 //         optionally also y without the class term     -> packed bf16 (N features)
 //   ROWS  y = acc + bias                               -> fp32 [M, N] row-major (logits)
 //
-// Tiling: a wave owns NO=4 output-feature tiles x NS=2 sample tiles (128 x 64); the four
-// waves of a workgroup share the weight tiles, staged through LDS in 32-KiB double-buffered
-// stages by direct global->LDS loads; activation fragments go straight from L2 to
-// registers (each feeds four MFMAs).
+// Tiling: a workgroup of four waves owns NO (4 or 2) output-feature tiles x 4 sample tiles; each
+// wave multiplies all NO weight tiles (shared through LDS) with its own sample tile.
 #include "common.h"
 
 namespace dvq {
 
 constexpr int kPgWaves = 4;
 constexpr int kPgNO = 4;
-constexpr int kPgNS = 2;
-constexpr int kPgStageKB = 4;   // k-blocks (of 32 features) per LDS stage
+constexpr int kPgStageKB = 2;   // k-blocks (of 32 features) per LDS stage
+constexpr int kPgRing = 4;      // stage buffers
 constexpr int kPgMaxTaps = 10;
 
 struct PgTapDev {
@@ -74,15 +72,29 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 
 enum { PG_PACK = 0, PG_GATE = 1, PG_ROWS = 2 };
 
-// grid: x = output-feature group (128 features; for GATE 64 + the matching 64 of the upper half),
-//       y = group of 4*NS sample tiles, z = job
-template <int EPI>
+// grid: x = output-feature group (NO tiles of 32; for GATE NO/2 + the matching NO/2 of the upper
+//       half), y = group of 4 sample tiles (one per wave), z = job.  One workgroup per CU.
+//
+// Pipeline: every operand byte reaches LDS by direct global->LDS loads (no register-destination
+// load inside the loop), in stages of KS=2 k-blocks (weights NO x 4 KiB shared by the four waves,
+// activations 4 KiB per wave) through a ring of R=4 stage buffers.  A wave waits only for ITS
+// loads of the stage it is about to read with a counted s_waitcnt vmcnt (two younger stages stay
+// in flight), then one s_barrier makes every wave's part visible and frees the buffer read two
+// stages ago, which is immediately refilled.  Products this small (M = 4096) are L2-latency
+// bound, not bandwidth bound: the depth of the ring is what buys throughput.
+template <int EPI, int NO>
 __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PgJobDev& job = jobs.j[blockIdx.z];
-    constexpr int NO = kPgNO, NS = kPgNS;
-    constexpr int STAGE_BYTES = NO * kPgStageKB * 2 * 1024;   // 32 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NS = 1;
+    constexpr int KS = kPgStageKB;                              // k-blocks per stage
+    constexpr int W_UNITS = NO * KS * 2;
+    constexpr int X_UNITS = kPgWaves * KS * 2;
+    constexpr int STAGE_BYTES = (W_UNITS + X_UNITS) * 1024;
+    constexpr int R = kPgRing;
+    constexpr int GLDS_PER_STAGE = W_UNITS / kPgWaves + KS * 2;  // per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int SB = (M + 31) / 32;
     const int n_ob = N / 32;
@@ -90,89 +102,77 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
     int ob[NO];
     if (EPI == PG_GATE) {
         const int half = n_ob / 2;
-        ob[0] = 2 * blockIdx.x; ob[1] = 2 * blockIdx.x + 1; ob[2] = half + 2 * blockIdx.x; ob[3] = half + 2 * blockIdx.x + 1;
+#pragma unroll
+        for (int t = 0; t < NO / 2; ++t) { ob[t] = (NO / 2) * blockIdx.x + t; ob[t + NO / 2] = half + (NO / 2) * blockIdx.x + t; }
     } else {
 #pragma unroll
         for (int t = 0; t < NO; ++t) ob[t] = NO * blockIdx.x + t;
     }
     int sb[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        sb[s] = (blockIdx.y * kPgWaves + wave) * NS + s;
-        if (sb[s] >= SB) sb[s] = SB - 1;   // surplus tiles recompute the last one; their stores are skipped
-    }
-    const bool live0 = ((blockIdx.y * kPgWaves + wave) * NS + 0) < SB;
-    const bool live1 = ((blockIdx.y * kPgWaves + wave) * NS + 1) < SB;
+    sb[0] = blockIdx.y * kPgWaves + wave;
+    const bool live0 = sb[0] < SB;
+    const bool live1 = false;
+    if (sb[0] >= SB) sb[0] = SB - 1;   // a surplus tile recomputes the last one; its stores are skipped
 
     f32x16 acc[NO][NS];
 #pragma unroll
     for (int t = 0; t < NO; ++t)
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][s][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[t][0][i] = 0.f;
 
-    // total stages over all taps
     int total_stages = 0;
-    for (int t = 0; t < job.n_taps; ++t) total_stages += (job.taps[t].kb + kPgStageKB - 1) / kPgStageKB;
+    for (int t = 0; t < job.n_taps; ++t) total_stages += job.taps[t].kb / KS;
 
-    // issue the direct-to-LDS loads of one stage: for each of the NO feature tiles, `nkb` k-blocks
-    // (2 units each) contiguous in the packed weight.  64 units max -> 16 per wave.
-    auto issue = [&](int tap, int kb0, int nkb, int buf) {
+    // one stage: W units [t][k][s2] then X units [wave][k][s2]
+    auto issue = [&](int tap, int kb0, int buf) {
         const char* w = job.taps[tap].w;
+        const char* x = job.taps[tap].x;
         const int KB = job.taps[tap].kb;
         char* dst = smem + buf * STAGE_BYTES;
-        const int units = NO * nkb * 2;
-        for (int u = wave; u < units; u += kPgWaves) {
-            const int t = u / (nkb * 2), q = u % (nkb * 2);
-            const char* src = w + ((int64_t)(ob[t] * KB + kb0) * 2 + q) * 1024 + lane * 16;
-            pg_glds16(src, dst + (t * kPgStageKB * 2 + q) * 1024);
+#pragma unroll
+        for (int i = 0; i < W_UNITS / kPgWaves; ++i) {
+            const int u = wave + kPgWaves * i;
+            const int t = u / (KS * 2), q = u % (KS * 2);
+            pg_glds16(w + ((int64_t)(ob[t] * KB + kb0) * 2 + q) * 1024 + lane * 16, dst + u * 1024);
         }
+#pragma unroll
+        for (int q = 0; q < KS * 2; ++q)
+            pg_glds16(x + (((int64_t)(kb0 + (q >> 1)) * SB + sb[0]) * 2 + (q & 1)) * 1024 + lane * 16,
+                      dst + (W_UNITS + wave * KS * 2 + q) * 1024);
     };
-
-    int tap = 0, kb0 = 0;   // stage being issued next
     auto advance = [&](int& tp, int& k0) {
-        k0 += kPgStageKB;
+        k0 += KS;
         if (k0 >= job.taps[tp].kb) { k0 = 0; ++tp; }
     };
-    {
-        const int nkb = (job.taps[0].kb - 0) < kPgStageKB ? job.taps[0].kb : kPgStageKB;
-        issue(0, 0, nkb, 0);
-        advance(tap, kb0);
+
+    int itap = 0, ikb = 0;   // next stage to issue
+    int issued = 0;
+    for (; issued < R - 1 && issued < total_stages; ++issued) {
+        issue(itap, ikb, issued % R);
+        advance(itap, ikb);
     }
-    int ctap = 0, ckb0 = 0;  // stage being computed
-    __syncthreads();
     for (int st = 0; st < total_stages; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < total_stages) {
-            const int rem = job.taps[tap].kb - kb0;
-            issue(tap, kb0, rem < kPgStageKB ? rem : kPgStageKB, buf ^ 1);
-            advance(tap, kb0);
+        // this wave's loads of stage st have landed when at most `younger` stages' worth are outstanding
+        const int younger = issued - st - 1;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * GLDS_PER_STAGE) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(GLDS_PER_STAGE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (issued < total_stages) {   // refill the buffer every wave finished reading before this barrier
+            issue(itap, ikb, issued % R);
+            advance(itap, ikb);
+            ++issued;
         }
-        {
-            const int rem = job.taps[ctap].kb - ckb0;
-            const int nkb = rem < kPgStageKB ? rem : kPgStageKB;
-            const char* xb = job.taps[ctap].x;
-            const char* wl = smem + buf * STAGE_BYTES + lane * 16;
-#pragma unroll 2
-            for (int k = 0; k < nkb; ++k) {
+        const char* sbuf = smem + (st % R) * STAGE_BYTES + lane * 16;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 xf[NS];
+        for (int q = 0; q < KS * 2; ++q) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sbuf + (W_UNITS + wave * KS * 2 + q) * 1024);
 #pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        xf[s] = *reinterpret_cast<const bf16x8*>(xb + (((int64_t)(ckb0 + k) * SB + sb[s]) * 2 + s2) * 1024 + lane * 16);
-#pragma unroll
-                    for (int t = 0; t < NO; ++t) {
-                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + (t * kPgStageKB * 2 + k * 2 + s2) * 1024);
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) acc[t][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[s], acc[t][s], 0, 0, 0);
-                    }
-                }
+            for (int t = 0; t < NO; ++t) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sbuf + (t * KS * 2 + q) * 1024);
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t][0], 0, 0, 0);
             }
-            advance(ctap, ckb0);
         }
-        __syncthreads();
     }
 
     // ---- epilogue.  register i of a tile <-> feature 32*ob + (i&3) + 8*(i>>2) + 4h, lane c <-> sample 32*sb + c
@@ -346,20 +346,35 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
         if (epilogue == PG_ROWS && !s.out_rows) return fail(DVQ_EINVAL, "prior_gemm: out_rows missing");
     }
     const int SB = (M + 31) / 32;
-    const dim3 grid(N / 128, (SB + kPgWaves * kPgNS - 1) / (kPgWaves * kPgNS), n_jobs);
-    const size_t lds = 2 * (size_t)kPgNO * kPgStageKB * 2 * 1024;
+    for (int j = 0; j < n_jobs; ++j)
+        for (int t = 0; t < jobs[j].n_taps; ++t)
+            if (jobs[j].taps[t].k_blocks % kPgStageKB) return fail(DVQ_EINVAL, "prior_gemm: k_blocks must be a multiple of %d", kPgStageKB);
+    // 128 output features per workgroup unless that leaves CUs without one; then 64
+    const int gy = (SB + kPgWaves - 1) / kPgWaves;
+    const int no = ((N / 128) * gy * n_jobs >= kNumCU || (N % 64) != 0 || (epilogue == PG_GATE && (N % 128) != 0)) ? 4 : 2;
+    const dim3 grid(N / (32 * no), gy, n_jobs);
+    const size_t lds = (size_t)kPgRing * (no * kPgStageKB * 2 + kPgWaves * kPgStageKB * 2) * 1024;
     hipStream_t st = as_stream(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(prior_gemm_kernel<PG_PACK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(prior_gemm_kernel<PG_GATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(prior_gemm_kernel<PG_ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        if (!ok) return fail(DVQ_ELAUNCH, "prior_gemm: cannot raise the dynamic LDS limit");
+        const void* fns[6] = {reinterpret_cast<const void*>(prior_gemm_kernel<PG_PACK, 2>), reinterpret_cast<const void*>(prior_gemm_kernel<PG_PACK, 4>),
+                              reinterpret_cast<const void*>(prior_gemm_kernel<PG_GATE, 2>), reinterpret_cast<const void*>(prior_gemm_kernel<PG_GATE, 4>),
+                              reinterpret_cast<const void*>(prior_gemm_kernel<PG_ROWS, 2>), reinterpret_cast<const void*>(prior_gemm_kernel<PG_ROWS, 4>)};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail(DVQ_ELAUNCH, "prior_gemm: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    if (epilogue == PG_PACK) hipLaunchKernelGGL((prior_gemm_kernel<PG_PACK>), grid, dim3(kPgWaves * 64), lds, st, dev, M, N, relu);
-    else if (epilogue == PG_GATE) hipLaunchKernelGGL((prior_gemm_kernel<PG_GATE>), grid, dim3(kPgWaves * 64), lds, st, dev, M, N, relu);
-    else if (epilogue == PG_ROWS) hipLaunchKernelGGL((prior_gemm_kernel<PG_ROWS>), grid, dim3(kPgWaves * 64), lds, st, dev, M, N, relu);
+    const dim3 blk(kPgWaves * 64);
+#define DVQ_PG_LAUNCH(E)                                                                           \
+    do {                                                                                           \
+        if (no == 4) hipLaunchKernelGGL((prior_gemm_kernel<E, 4>), grid, blk, lds, st, dev, M, N, relu); \
+        else hipLaunchKernelGGL((prior_gemm_kernel<E, 2>), grid, blk, lds, st, dev, M, N, relu);        \
+    } while (0)
+    if (epilogue == PG_PACK) DVQ_PG_LAUNCH(PG_PACK);
+    else if (epilogue == PG_GATE) DVQ_PG_LAUNCH(PG_GATE);
+    else if (epilogue == PG_ROWS) DVQ_PG_LAUNCH(PG_ROWS);
     else return fail(DVQ_EINVAL, "prior_gemm: unknown epilogue %d", epilogue);
+#undef DVQ_PG_LAUNCH
     return check_launch("prior_gemm");
 }

@@ -143,6 +143,7 @@ class GatedPixelCNN(nn.Module):
         self._packed_key = None
         self._packed = None
         self._bufs = {}
+        self.use_graph = True                  # replay generate() as a captured HIP graph (bf16 kernels)
 
     def forward(self, x, label):
         shp = x.size() + (-1,)
@@ -188,24 +189,48 @@ class GatedPixelCNN(nn.Module):
                 HV=[[e(2 * d) for _ in range(W)] for _ in range(L)],
                 XH=[[e(d) for _ in range(L + 1)] for _ in range(2)],
                 OUT=e(d), HID=e(self.output_conv[0].out_channels), Z=e(d, True),
-                logits=torch.empty(B, self.output_conv[2].out_channels, dtype=torch.float32, device=dev))}
+                logits=torch.empty(B, self.output_conv[2].out_channels, dtype=torch.float32, device=dev),
+                emb=self.embedding.weight.detach().float().contiguous(),
+                label=torch.zeros(B, dtype=torch.int64, device=dev),
+                u=torch.zeros(B, H * W, dtype=torch.float64, device=dev), graph=None, x=None)}
         return self._bufs[key]
 
     @torch.no_grad()
     def _generate_hip(self, label, shape, B, generator, return_probs, uniforms):
-        """generate() on the fused bf16 kernels: per grid row one launch per layer for the
-        vertical stack (3 cells at once, gate fused), per cell two launches per layer for the
-        horizontal stack (taps + projected vertical features + gate; residual 1x1), two for
-        the head."""
+        """generate() on the fused bf16 kernels.  With explicit uniforms the whole procedure is a
+        fixed sequence of ~370 launches over persistent buffers; it is captured once per batch
+        size into a HIP graph and replayed, because issuing that many small dependent launches
+        from Python costs more than running them."""
         H, W = shape
-        layers, (wo1, bo1, wo2, bo2) = self._prepared_hip()
         dev = self.embedding.weight.device
+        self._prepared_hip()
         bufs = self._act_buffers(B, H, W, dev)
+        bufs["label"].copy_(label.reshape(-1).to(torch.int64))
+        if uniforms is None or return_probs or not self.use_graph:
+            return self._run_hip(bufs, shape, B, generator, return_probs, uniforms)
+        bufs["u"].copy_(uniforms)
+        if bufs.get("graph") is None:
+            self._run_hip(bufs, shape, B, None, False, bufs["u"])        # warm-up outside capture
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                bufs["x"] = self._run_hip(bufs, shape, B, None, False, bufs["u"])
+            bufs["graph"] = g
+        bufs["graph"].replay()
+        return bufs["x"].clone()
+
+    def _run_hip(self, bufs, shape, B, generator, return_probs, uniforms):
+        """Per grid row one launch per layer for the vertical stack (3 cells at once, gate fused), per
+        cell two launches per layer for the horizontal stack (taps + projected vertical features +
+        gate; residual 1x1), two for the head, then the sample and its embedding."""
+        H, W = shape
+        layers, (wo1, bo1, wo2, bo2) = self._packed
+        dev = self.embedding.weight.device
         XV, HV, XHb, OUT, HID, Z, logits = (bufs[k] for k in ("XV", "HV", "XH", "OUT", "HID", "Z", "logits"))
         L, d = len(layers), self.dim
         kb = d // 32
-        emb = self.embedding.weight.detach().float().contiguous()
-        label = label.reshape(-1).to(torch.int64).contiguous()
+        emb = bufs["emb"]
+        label = bufs["label"]
         x = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
         n_out = logits.shape[1]
         probs_all = []

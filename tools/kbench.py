@@ -83,6 +83,21 @@ def linear():
         print(f"linear M={M_} K={K} N={N}: {ms:.4f} ms  {2.0 * M_ * K * N / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
+def prior():
+    from network.gen_net import GenNet
+    from dvq_hip import rng
+    model = GenNet()
+    model.load_state_dict(synth.gennet_state_dict(0))
+    pr = model.GatedPixelCNN.to(dev).eval()
+    for B in (4096, 512, 1):
+        lab = torch.randint(0, 128, (B,), device=dev)
+        u = rng.uniforms(torch.arange(B, device=dev), 9, 0)
+        for dt in (torch.bfloat16, torch.float32):
+            pr.compute_dtype = dt
+            ms = timeit(lambda: pr.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u), iters=3, warm=1)
+            print(f"prior.generate B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  ({1.22e9 * B / ms / 1e9:7.1f} TFLOP/s useful)", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pointnet", "vq", "mano", "linear"]
     for w in which:
