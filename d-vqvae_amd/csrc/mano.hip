@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kManoThreads, 2) void mano_lbs_kernel(
     int B, int V, int ncomp, const float* __restrict__ v_shaped, const float* __restrict__ joints,
     const float* __restrict__ posedirs, const float* __restrict__ weights, const float* __restrict__ comps,
     const float* __restrict__ pose_mean, const int* __restrict__ parents, float* __restrict__ verts_out,
-    float* __restrict__ joints_out, float* __restrict__ full_pose_out) {
+    float* __restrict__ joints_out, float* __restrict__ full_pose_out, float* __restrict__ v_posed_out) {
     __shared__ float sR[kHB][kJ][9];     // rotation matrices
     __shared__ __attribute__((aligned(16))) float sA[kHB][kJ][12];    // relative transforms, upper 3x4
     __shared__ float sT[kHB][kJ][12];    // world transforms, upper 3x4
@@ -193,6 +193,10 @@ __global__ __launch_bounds__(kManoThreads, 2) void mano_lbs_kernel(
                 }
             }
             float* dst = verts_out + ((int64_t)(b0 + hnd) * V + v) * 3;
+            if (v_posed_out) {   // kept for dvq_mano_lbs_backward
+                float* vpd = v_posed_out + ((int64_t)(b0 + hnd) * V + v) * 3;
+                vpd[0] = px; vpd[1] = py; vpd[2] = pz;
+            }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 float r = T[a * 4 + 0] * px;
@@ -210,7 +214,8 @@ __global__ __launch_bounds__(kManoThreads, 2) void mano_lbs_kernel(
 using namespace dvq;
 
 extern "C" int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float* transl, int B,
-                            const DvqManoConsts* m, float* verts_out, float* joints_out, float* full_pose_out, void* stream) {
+                            const DvqManoConsts* m, float* verts_out, float* joints_out, float* full_pose_out, float* v_posed_out,
+                            void* stream) {
     if (B < 0) return fail(DVQ_EINVAL, "mano: negative batch");
     if (B == 0) return DVQ_OK;
     if (!m || !global_orient || !hand_pose || !verts_out) return fail(DVQ_EINVAL, "mano: null pointer");
@@ -221,6 +226,6 @@ extern "C" int dvq_mano_lbs(const float* global_orient, const float* hand_pose, 
     const int grid = (B + kHB - 1) / kHB;
     hipLaunchKernelGGL(mano_lbs_kernel, dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
                        m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
-                       m->parents, verts_out, joints_out, full_pose_out);
+                       m->parents, verts_out, joints_out, full_pose_out, v_posed_out);
     return check_launch("mano_lbs");
 }

@@ -28,6 +28,11 @@ class DvqManoConsts(ctypes.Structure):
                 ("pose_mean", c_void_p), ("parents", c_void_p)]
 
 
+class DvqHandMesh(ctypes.Structure):
+    _fields_ = [("n_verts", c_int), ("n_faces", c_int), ("faces", c_void_p), ("vert_face_ptr", c_void_p),
+                ("vert_face", c_void_p), ("contact_mask", c_void_p)]
+
+
 class DvqPriorTap(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("k_blocks", c_int)]
 
@@ -56,7 +61,12 @@ SIGNATURES = {
     "dvq_prior_pack_weight": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_gemm": (c_int, [POINTER(DvqPriorJob), c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p]),
+    "dvq_mano_lbs_backward": (c_int, [c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "dvq_tta_contact_grad": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, POINTER(DvqHandMesh), c_float,
+                                     c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

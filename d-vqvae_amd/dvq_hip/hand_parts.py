@@ -24,3 +24,17 @@ _RUNS = (
 
 HAND_PARTS = [[v for first, count in runs for v in range(first, first + count)] for runs in _RUNS]
 PART_SIZES = [len(p) for p in HAND_PARTS]  # [83, 123, 120, 122, 121, 212]
+
+# Vertices that may touch the object in the contact loss of the test-time adaptation
+# (DVQ-VAE/utils/loss.py:81-93): five fingertip regions and eight palm vertices, run-length
+# encoded as above, in the reference's order (thumb, index, middle, ring, little, palm); 204
+# distinct vertices.
+_CONTACT_RUNS = (
+    ((697, 4), (712, 4), (737, 5), (743, 4), (748, 3), (753, 16)),
+    ((46, 4), (164, 4), (194, 2), (223, 1), (237, 2), (280, 2), (298, 1), (301, 1), (317, 1), (320, 1), (323, 11), (340, 16)),
+    ((356, 4), (375, 2), (386, 2), (396, 2), (402, 2), (413, 1), (429, 1), (433, 12), (452, 5), (459, 9)),
+    ((468, 4), (484, 3), (496, 2), (506, 2), (513, 2), (524, 1), (545, 9), (555, 1), (563, 5), (570, 1), (572, 7)),
+    ((580, 4), (600, 3), (614, 2), (624, 2), (630, 2), (641, 1), (663, 6), (670, 1), (672, 1), (680, 5), (686, 10)),
+    ((73, 1), (96, 1), (98, 2), (772, 1), (774, 2), (777, 1)),
+)
+CONTACT_VERTS = [v for runs in _CONTACT_RUNS for first, count in runs for v in range(first, first + count)]

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import DVQ_BF16, DVQ_F32, DvqManoConsts, DvqPointMlp, DvqPriorJob
+from ._lib import DVQ_BF16, DVQ_F32, DvqHandMesh, DvqManoConsts, DvqPointMlp, DvqPriorJob
 
 
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
@@ -190,18 +190,79 @@ def linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], relu: bo
 
 # ------------------------------------------------------------------------- MANO
 def mano_lbs(global_orient, hand_pose, transl, consts: DvqManoConsts, n_verts: int,
-             want_joints: bool = True, want_full_pose: bool = False):
+             want_joints: bool = True, want_full_pose: bool = False, want_v_posed: bool = False,
+             verts: Optional[torch.Tensor] = None, v_posed: Optional[torch.Tensor] = None):
+    """MANO forward.  Returns (verts, joints, full_pose) and, with want_v_posed, the blend-shaped rest
+    vertices the backward pass needs as a fourth element.  `verts` / `v_posed` may be preallocated."""
     _need_gpu(global_orient, hand_pose, transl)
     B = hand_pose.shape[0]
     dev = hand_pose.device
-    verts = torch.empty(B, n_verts, 3, dtype=torch.float32, device=dev)
+    if verts is None:
+        verts = torch.empty(B, n_verts, 3, dtype=torch.float32, device=dev)
     joints = torch.empty(B, 16, 3, dtype=torch.float32, device=dev) if want_joints else None
     full = torch.empty(B, 48, dtype=torch.float32, device=dev) if want_full_pose else None
+    if want_v_posed and v_posed is None:
+        v_posed = torch.empty(B, n_verts, 3, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _timed("mano_lbs", (B,), hand_pose):
         rc = _lib.load().dvq_mano_lbs(_p(global_orient), _p(hand_pose), _p(transl), B, ctypes.byref(consts),
-                                      _p(verts), _p(joints), _p(full), _stream(hand_pose))
+                                      _p(verts), _p(joints), _p(full), _p(v_posed) if want_v_posed else None,
+                                      _stream(hand_pose))
     _lib.check(rc, "dvq_mano_lbs")
+    if want_v_posed:
+        return verts, joints, full, v_posed
     return verts, joints, full
+
+
+def mano_lbs_backward(global_orient, hand_pose, consts: DvqManoConsts, v_posed, grad_verts, out=None):
+    """(dL/dglobal_orient [B,3], dL/dhand_pose [B,ncomp], dL/dtransl [B,3]) from dL/dvertices.  `out` may be
+    a preallocated triple."""
+    _need_gpu(global_orient, hand_pose, v_posed, grad_verts)
+    B = hand_pose.shape[0]
+    dev = hand_pose.device
+    if out is None:
+        out = (torch.empty(B, 3, dtype=torch.float32, device=dev), torch.empty(B, hand_pose.shape[1], dtype=torch.float32, device=dev),
+               torch.empty(B, 3, dtype=torch.float32, device=dev))
+    g_go, g_hp, g_tr = out
+    with torch.cuda.device(dev), _timed("mano_lbs_backward", (B,), hand_pose):
+        rc = _lib.load().dvq_mano_lbs_backward(_p(global_orient), _p(hand_pose), B, ctypes.byref(consts), _p(v_posed),
+                                               _p(grad_verts), _p(g_go), _p(g_hp), _p(g_tr), _stream(hand_pose))
+    _lib.check(rc, "dvq_mano_lbs_backward")
+    return g_go, g_hp, g_tr
+
+
+# ------------------------------------------------------- test-time adaptation
+def tta_contact_grad(obj: torch.Tensor, verts: torch.Tensor, mesh: DvqHandMesh, contact_dist_sq: float,
+                     penetr_scale: float, contact_scale: float, w_penetr: float, w_contact: float,
+                     grad_verts: Optional[torch.Tensor] = None, losses: Optional[torch.Tensor] = None,
+                     nn_idx: Optional[torch.Tensor] = None, points_last: bool = True):
+    """obj: [B,C>=3,N] channel-major cloud as the datasets produce it (points_last; only its first three
+    channels are read) or [B,N,3]; any strides.  verts [B,V,3].  nn_idx: optional int32 [B,N] output.
+    Returns (grad_verts [B,V,3], losses [B,2] = (penetr, contact))."""
+    _need_gpu(verts, grad_verts, losses, nn_idx)
+    if not obj.is_cuda:
+        raise RuntimeError("dvq_hip kernels need tensors on a HIP device (got a CPU tensor); there is no CPU fallback")
+    if obj.dtype != torch.float32 or verts.dtype != torch.float32:
+        raise RuntimeError("tta_contact_grad: float32 expected")
+    B, V = verts.shape[0], verts.shape[1]
+    if obj.dim() != 3 or obj.shape[0] != B or obj.shape[1 if points_last else 2] < 3:
+        raise RuntimeError("tta_contact_grad: obj must be [B,C>=3,N] (points_last) or [B,N,3]")
+    if points_last:
+        n_points, sb, sc, sp = obj.shape[2], obj.stride(0), obj.stride(1), obj.stride(2)
+    else:
+        n_points, sb, sc, sp = obj.shape[1], obj.stride(0), obj.stride(2), obj.stride(1)
+    if nn_idx is not None and (nn_idx.dtype != torch.int32 or nn_idx.numel() != B * n_points):
+        raise RuntimeError("tta_contact_grad: nn_idx must be int32 [B,N]")
+    dev = verts.device
+    if grad_verts is None:
+        grad_verts = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    if losses is None:
+        losses = torch.empty(B, 2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("tta_contact_grad", (B, n_points), verts):
+        rc = _lib.load().dvq_tta_contact_grad(_p(obj), sb, sc, sp, n_points, _p(verts), B, ctypes.byref(mesh), contact_dist_sq,
+                                              penetr_scale, contact_scale, w_penetr, w_contact, _p(grad_verts), _p(losses),
+                                              _p(nn_idx), _stream(verts))
+    _lib.check(rc, "dvq_tta_contact_grad")
+    return grad_verts, losses
 
 
 # ------------------------------------------------------------------------ prior

@@ -41,6 +41,30 @@ def _f32(a):
     return torch.as_tensor(to_np(a), dtype=torch.float32)
 
 
+class _LbsFunction(torch.autograd.Function):
+    """Differentiable vertices for callers that optimise the pose through the layer, as the
+    reference's test-time adaptation does with autograd (DVQ-VAE/gen_HDMO_TTA.py:136-151).
+    Joints and full_pose are returned without a gradient path."""
+
+    @staticmethod
+    def forward(ctx, go, hp, tr, module):
+        consts = module._device_consts()
+        verts, joints, full, vp = ops.mano_lbs(go, hp, tr, consts, module.v_template.shape[0], True, True,
+                                               want_v_posed=True)
+        ctx.save_for_backward(go, hp, vp)
+        ctx.module = module
+        ctx.has_transl = tr is not None
+        ctx.mark_non_differentiable(joints, full)
+        return verts, joints, full
+
+    @staticmethod
+    def backward(ctx, g_verts, g_joints, g_full):
+        go, hp, vp = ctx.saved_tensors
+        g_go, g_hp, g_tr = ops.mano_lbs_backward(go, hp, ctx.module._device_consts(), vp,
+                                                 g_verts.to(torch.float32).contiguous())
+        return g_go, g_hp, (g_tr if ctx.has_transl else None), None
+
+
 class MANO(nn.Module):
     NUM_BODY_JOINTS = 1
     NUM_HAND_JOINTS = 15
@@ -174,8 +198,10 @@ class MANO(nn.Module):
         if hasattr(self, 'betas') and self.betas.shape[0] > 1 and bool((self.betas != self.betas[0:1]).any()):
             raise NotImplementedError("per-row values in the module's own betas parameter are not supported")
         vertices = joints = full_pose = None
-        hp = hand_pose.detach().to(torch.float32).contiguous()
-        go = global_orient.detach().to(torch.float32).contiguous()
+        want_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (global_orient, hand_pose, transl))
+        keep = (lambda t: t) if want_grad else (lambda t: t.detach())
+        hp = keep(hand_pose).to(torch.float32).contiguous()
+        go = keep(global_orient).to(torch.float32).contiguous()
         B = hp.shape[0]
 
         def rows(t, what):   # the module's own batch-1 defaults broadcast, as in the reference
@@ -187,10 +213,12 @@ class MANO(nn.Module):
         go = rows(go, "global_orient")
         tr = None
         if transl is not None:
-            tr = rows(transl.detach().to(torch.float32).contiguous(), "transl")
+            tr = rows(keep(transl).to(torch.float32).contiguous(), "transl")
         if return_verts:
-            consts = self._device_consts()
-            vertices, joints, full_pose = ops.mano_lbs(go, hp, tr, consts, self.v_template.shape[0], True, True)
+            if want_grad:
+                vertices, joints, full_pose = _LbsFunction.apply(go, hp, tr, self)
+            else:
+                vertices, joints, full_pose = ops.mano_lbs(go, hp, tr, self._device_consts(), self.v_template.shape[0], True, True)
             if return_tips:
                 joints = self.add_joints(vertices, joints)
             if self.joint_mapper is not None:

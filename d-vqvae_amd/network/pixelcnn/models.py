@@ -317,7 +317,7 @@ class GatedPixelCNN(nn.Module):
 
         def lin(bias, pairs, n_out):
             """bias + sum_k a_k @ w_k, fp32 [B, n_out]"""
-            acc = bias.unsqueeze(0).expand(B, n_out).contiguous()
+            acc = bias.unsqueeze(0).repeat(B, 1)        # a fresh buffer (expand().contiguous() aliases the bias when B == 1)
             for a, w in pairs:
                 if a.dtype == torch.float32:
                     acc.addmm_(a, w)

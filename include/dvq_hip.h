@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 100   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 101   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -120,7 +120,9 @@ int dvq_linear(const float* x, int64_t ldx, const float* W, const float* b, int 
  * zero betas), so v_shaped and the rest joints are constants precomputed on the host.
  *
  * global_orient: [B,3]; hand_pose: [B,ncomps] PCA coefficients; transl: [B,3] or NULL.
- * verts_out: [B,V,3]; joints_out: [B,16,3] or NULL; full_pose_out: [B,48] or NULL.
+ * verts_out: [B,V,3]; joints_out: [B,16,3] or NULL; full_pose_out: [B,48] or NULL;
+ * v_posed_out: [B,V,3] or NULL -- the vertices after the pose blend shapes and before skinning
+ * (lbs.py:101), which dvq_mano_lbs_backward needs.
  */
 typedef struct {
     int n_verts;              /* V (778)                                  */
@@ -136,7 +138,48 @@ typedef struct {
 
 int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float* transl, int B,
                  const DvqManoConsts* m, float* verts_out, float* joints_out, float* full_pose_out,
-                 void* stream);
+                 float* v_posed_out, void* stream);
+
+/* Vector-Jacobian product of dvq_mano_lbs's vertices: what autograd computes for the reference's
+ * MANO layer when a loss on the vertices is back-propagated to the pose parameters, as the
+ * test-time adaptation does (reference: DVQ-VAE/gen_HDMO_TTA.py:136-151).  Same inputs as the
+ * forward call plus its v_posed output and grad_verts = dL/dvertices [B,V,3].
+ * Outputs (each nullable): dL/dglobal_orient [B,3], dL/dhand_pose [B,ncomps], dL/dtransl [B,3].
+ * The shape coefficients have no gradient (the forward ignores them). */
+int dvq_mano_lbs_backward(const float* global_orient, const float* hand_pose, int B, const DvqManoConsts* m,
+                          const float* v_posed, const float* grad_verts, float* grad_global_orient,
+                          float* grad_hand_pose, float* grad_transl, void* stream);
+
+/* ------------------------------------------------- test-time adaptation: contact / penetration
+ * Loss and its gradient w.r.t. the hand vertices for the refinement loop of
+ * DVQ-VAE/gen_HDMO_TTA.py:141-151, per grasp (the reference's batch of one, row by row):
+ *   nn(i)      nearest hand vertex of object point i, squared distance d_i   (utils_loss.py:7-24)
+ *   interior_i (v_nn(i) - o_i) . normal(v_nn(i)) > 0                          (utils_loss.py:27-45)
+ *   penetr  = penetr_scale * sum_{interior} d_i                               (loss.py:120)
+ *   contact = contact_scale * sum_{d_i < contact_dist_sq} d'_i / #{d_i < contact_dist_sq},
+ *             d'_i = squared distance to the nearest vertex of the contact set (loss.py:93-101,126)
+ *   loss    = w_contact * contact + w_penetr * penetr                         (gen_HDMO_TTA.py:150)
+ * Vertex normals are the sums of the incident faces' area-weighted normals (loss.py:116-117; only
+ * their direction is used).  A grasp with no point closer than the threshold has contact = 0.
+ * The nearest-neighbour masks are constants of the gradient, as in the reference.
+ *
+ * obj: coordinate c of point i of grasp b at obj[b*obj_batch_stride + c*obj_chan_stride + i*obj_point_stride]
+ *      ([B,4,N] clouds: 4N, N, 1).  verts: [B,V,3].
+ * grad_verts: [B,V,3] = dloss/dverts.  losses: [B,2] = (penetr, contact).  nn_idx: int [B,N] or NULL.
+ */
+typedef struct {
+    int n_verts;
+    int n_faces;
+    const int* faces;                  /* [F,3]                                            */
+    const int* vert_face_ptr;          /* [V+1] offsets into vert_face                     */
+    const int* vert_face;              /* faces incident to each vertex, grouped by vertex */
+    const unsigned char* contact_mask; /* [V] 1 = vertex belongs to the contact set        */
+} DvqHandMesh;
+
+int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, int64_t obj_chan_stride, int64_t obj_point_stride,
+                         int n_points, const float* verts, int B, const DvqHandMesh* mesh, float contact_dist_sq,
+                         float penetr_scale, float contact_scale, float w_penetr, float w_contact,
+                         float* grad_verts, float* losses, int* nn_idx, void* stream);
 
 /* ------------------------------------------------------------ prior (PixelCNN)
  * Matrix products of the GatedPixelCNN prior evaluated cell by cell (reference:

@@ -86,6 +86,10 @@ def test_prior_incremental_sampling_equals_full_forwards():
     # same uniforms -> same grid, for the whole batch or for a shard of it
     x2 = prior.generate(None, lab[5:9], shape=(3, 3), batch_size=4, uniforms=u[5:9])
     assert torch.equal(x2, x[5:9])
+    # a batch of one (the reference's only batch size), twice: no state may leak from call to call
+    for _ in range(2):
+        x1, p1 = prior.generate(None, lab[7:8], shape=(3, 3), batch_size=1, uniforms=u[7:8], return_probs=True)
+        assert torch.equal(x1[0], x[7]) and (p1[0] - probs[7]).abs().max().item() <= 1e-5
     # oracle (CPU restatement of the reference) agrees on the distributions too
     sd = synth.gennet_state_dict(0, with_prior=True)
     _, p_cpu = O.pixelcnn_generate(sd, lab[:3].cpu(), (3, 3), forced=x[:3].cpu())
@@ -116,6 +120,8 @@ def test_prior_bf16_kernels_vs_fp32():
     prior.compute_dtype = torch.bfloat16
     x16b = prior.generate(None, lab[32:77].contiguous(), shape=(3, 3), batch_size=45, uniforms=u[32:77].contiguous())
     assert torch.equal(x16b, x16[32:77])       # independent of batch composition
+    x16c = prior.generate(None, lab[40:41].contiguous(), shape=(3, 3), batch_size=1, uniforms=u[40:41].contiguous())
+    assert torch.equal(x16c[0], x16[40])       # and of batch size, down to one
 
 
 def test_gen_bf16_stated_tolerance():
