@@ -111,6 +111,35 @@ def cpu_baseline(with_prior, budget_s=12.0, batch=16):
                       f"prior {'sampled' if with_prior else 'teacher-forced'}, {el:.1f} s"}
 
 
+def tta_bench(gen, obj, first_id, device, iters=30):
+    """Refinement loop (the step after generation in the reference's adaptation script): time per
+    SGD iteration for this batch on the GPU, and the CPU oracle's autograd loop on a small sample."""
+    from dvq_hip.tta import GraspRefiner, ITERS
+    param = gen.generate(obj, first_id=first_id)["recon_param"]
+    r = GraspRefiner(gen.rh_mano)
+    r.refine(obj, param, iters=3)                       # builds the buffers and captures the graph
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    r.refine(obj, param, iters=iters)
+    torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) * 1e3 / iters
+    B = obj.shape[0]
+    out = {"grasps": B, "ms_per_iteration": round(ms, 4), "grasp_iterations_per_s": round(B / ms * 1e3, 1),
+           "refined_grasps_per_s_at_300_iterations": round(B / (ms * ITERS) * 1e3, 1)}
+    from oracle import tta_oracle as T
+    from dvq_hip.hand_parts import CONTACT_VERTS
+    sd = synth.mano_state_dict(0)
+    nb, ni = 4, 3
+    pc, oc = param[:nb].cpu(), obj[:nb, :3].permute(0, 2, 1).contiguous().cpu()
+    T.refine(sd, sd["faces_tensor"], oc, pc, CONTACT_VERTS, iters=1)
+    t0 = time.perf_counter()
+    T.refine(sd, sd["faces_tensor"], oc, pc, CONTACT_VERTS, iters=ni)
+    el = time.perf_counter() - t0
+    out["cpu_oracle_grasp_iterations_per_s"] = round(nb * ni / el, 2)
+    out["cpu_sample"] = f"{nb} grasps x {ni} iterations, torch autograd on {torch.get_num_threads()} threads"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +227,7 @@ def main():
         variants[f"{'fp32' if args.dtype == 'bf16' else 'bf16'}_prior_forced"] = round(B * 2 / el, 1)
         dvq_hip.set_compute_dtype(gen.model, tdtype)
         result["variants_grasps_per_s"] = variants
+        result["tta_refinement"] = tta_bench(gen, obj, first_id, device)
         del obj
         torch.cuda.empty_cache()
         result["vq_argmin"] = vq_microbench(device)

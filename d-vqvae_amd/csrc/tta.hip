@@ -32,24 +32,26 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
-struct TtaPoint {
-    float x, y, z;
-    float best, cbest;
-    int bi, ci;
-};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kTtaPts = 4;   // object points per thread and pass (two packed-fp32 pairs)
 
+// Vertices are searched in `order`: the n_contact vertices of the contact set first, then the others.
+// The nearest contact-set vertex is then simply the running minimum at the end of the first group, and
+// every (point, vertex) pair costs three packed subtract/multiply-add pairs and one compare-select, not two.
+// Exact distance ties resolve to the vertex met first in that order.
 __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
-    const float* __restrict__ obj, int64_t sb, int64_t sc, int64_t sp, int N, const float* __restrict__ verts, int V,
+    const float* __restrict__ obj, int64_t sb, int64_t sc, int64_t sp, int N, const float* __restrict__ verts, int V, int nC,
     const int* __restrict__ faces, const int* __restrict__ vf_ptr, const int* __restrict__ vf,
-    const unsigned char* __restrict__ cmask, float thresh, float penetr_scale, float contact_scale, float w_penetr,
+    const int* __restrict__ order, float thresh, float penetr_scale, float contact_scale, float w_penetr,
     float w_contact, float* __restrict__ grad_verts, float* __restrict__ losses, int* __restrict__ nn_idx) {
     extern __shared__ __attribute__((aligned(16))) char tta_smem[];
-    f32x4* hv = reinterpret_cast<f32x4*>(tta_smem);                       // x, y, z, 0 (contact set) / +inf
-    f32x4* hn = hv + V;                                                  // vertex normal (unnormalised)
-    long long* sumP = reinterpret_cast<long long*>(hn + V);              // [V][3] fixed-point sum of o_i, penetrating points
-    long long* sumC = sumP + 3 * V;                                      // [V][3] same, contact points
+    f32x4* hv = reinterpret_cast<f32x4*>(tta_smem);                       // [k] x, y, z of vertex order[k]; w = order[k] as bits
+    f32x4* hn = hv + V;                                                  // [k] vertex normal (unnormalised)
+    long long* sumP = reinterpret_cast<long long*>(hn + V);              // [k][3] fixed-point sum of o_i, penetrating points
+    long long* sumC = sumP + 3 * V;                                      // [k][3] same, contact points
     int* cntP = reinterpret_cast<int*>(sumC + 3 * V);
     int* cntC = cntP + V;
+    int* rank = cntC + V;                                                // vertex id -> k
     __shared__ float sPen[kTtaWaves], sCon[kTtaWaves];
     __shared__ int sN[kTtaWaves];
 
@@ -58,22 +60,25 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
     const float* vb = verts + (int64_t)b * V * 3;
     const float inf = __builtin_inff();
 
-    for (int v = tid; v < V; v += kTtaThreads) {
+    for (int k = tid; k < V; k += kTtaThreads) {
+        const int v = order[k];
         f32x4 h;
         h[0] = vb[3 * v]; h[1] = vb[3 * v + 1]; h[2] = vb[3 * v + 2];
-        h[3] = cmask[v] ? 0.f : inf;
-        hv[v] = h;
-        cntP[v] = 0; cntC[v] = 0;
+        h[3] = __int_as_float(v);
+        hv[k] = h;
+        rank[v] = k;
+        cntP[k] = 0; cntC[k] = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { sumP[3 * v + c] = 0; sumC[3 * v + c] = 0; }
+        for (int c = 0; c < 3; ++c) { sumP[3 * k + c] = 0; sumC[3 * k + c] = 0; }
     }
     __syncthreads();
     // vertex normals: sum of (p1 - p0) x (p2 - p0) over the incident faces
-    for (int v = tid; v < V; v += kTtaThreads) {
+    for (int k = tid; k < V; k += kTtaThreads) {
+        const int v = order[k];
         float nx = 0.f, ny = 0.f, nz = 0.f;
-        for (int k = vf_ptr[v]; k < vf_ptr[v + 1]; ++k) {
-            const int f = vf[k];
-            const f32x4 p0 = hv[faces[3 * f]], p1 = hv[faces[3 * f + 1]], p2 = hv[faces[3 * f + 2]];
+        for (int q = vf_ptr[v]; q < vf_ptr[v + 1]; ++q) {
+            const int f = vf[q];
+            const f32x4 p0 = hv[rank[faces[3 * f]]], p1 = hv[rank[faces[3 * f + 1]]], p2 = hv[rank[faces[3 * f + 2]]];
             const float ux = p1[0] - p0[0], uy = p1[1] - p0[1], uz = p1[2] - p0[2];
             const float wx = p2[0] - p0[0], wy = p2[1] - p0[1], wz = p2[2] - p0[2];
             nx += uy * wz - uz * wy;
@@ -81,56 +86,97 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
             nz += ux * wy - uy * wx;
         }
         f32x4 n; n[0] = nx; n[1] = ny; n[2] = nz; n[3] = 0.f;
-        hn[v] = n;
+        hn[k] = n;
     }
     __syncthreads();
 
     float pen = 0.f, con = 0.f;
     int ncon = 0;
     const float* ob = obj + (int64_t)b * sb;
-    for (int i0 = tid; i0 < N; i0 += 2 * kTtaThreads) {
-        TtaPoint p[2];
+    for (int i0 = tid; i0 < N; i0 += kTtaPts * kTtaThreads) {
+        f32x2 px[2], py[2], pz[2], best[2];
+        int bi[kTtaPts];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kTtaPts; ++q) {
             int i = i0 + q * kTtaThreads;
             if (i >= N) i = i0;
-            p[q].x = ob[i * sp]; p[q].y = ob[sc + i * sp]; p[q].z = ob[2 * sc + i * sp];
-            p[q].best = inf; p[q].cbest = inf; p[q].bi = 0; p[q].ci = 0;
+            px[q >> 1][q & 1] = ob[i * sp]; py[q >> 1][q & 1] = ob[sc + i * sp]; pz[q >> 1][q & 1] = ob[2 * sc + i * sp];
+            best[q >> 1][q & 1] = inf;
+            bi[q] = 0;
         }
-        for (int v = 0; v < V; ++v) {
-            const f32x4 h = hv[v];
+        // Four vertices at a time: only the group's minimum is compared with the running best and only
+        // the group's first vertex is remembered; the winner inside the group is resolved after the scan.
+        auto scan = [&](int k0, int k1) {
+            for (int kg = k0; kg < k1; kg += 4) {
+                f32x2 d[4][2];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float dx = p[q].x - h[0], dy = p[q].y - h[1], dz = p[q].z - h[2];
-                const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                if (d < p[q].best) { p[q].best = d; p[q].bi = v; }
-                const float e = d + h[3];
-                if (e < p[q].cbest) { p[q].cbest = e; p[q].ci = v; }
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kg + u < k1 ? kg + u : k1 - 1;
+                    const f32x4 h = hv[k];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const f32x2 dx = px[g] - h[0], dy = py[g] - h[1], dz = pz[g] - h[2];
+                        d[u][g] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float m = fminf(fminf(d[0][g][e], d[1][g][e]), fminf(d[2][g][e], d[3][g][e]));
+                        if (m < best[g][e]) { best[g][e] = m; bi[2 * g + e] = kg; }
+                    }
             }
-        }
+        };
+        // first vertex of the group [kg, min(kg+4, k1)) at the group's minimum distance
+        auto resolve = [&](int q, int kg, int k1) {
+            const float ox = px[q >> 1][q & 1], oy = py[q >> 1][q & 1], oz = pz[q >> 1][q & 1];
+            float bd = inf;
+            int bk = kg;
+            for (int k = kg; k < kg + 4 && k < k1; ++k) {
+                const f32x4 h = hv[k];
+                const float dx = ox - h[0], dy = oy - h[1], dz = oz - h[2];
+                const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                if (dd < bd) { bd = dd; bk = k; }
+            }
+            return bk;
+        };
+        scan(0, nC);
+        float cbest[kTtaPts];
+        int ci[kTtaPts];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kTtaPts; ++q) { cbest[q] = best[q >> 1][q & 1]; ci[q] = resolve(q, bi[q], nC); bi[q] = ci[q]; }
+        // the running best now names an exact vertex; mark it so that a later group start is distinguishable
+        int exact[kTtaPts];
+#pragma unroll
+        for (int q = 0; q < kTtaPts; ++q) { exact[q] = bi[q]; bi[q] = -1; }
+        scan(nC, V);
+#pragma unroll
+        for (int q = 0; q < kTtaPts; ++q) bi[q] = bi[q] < 0 ? exact[q] : resolve(q, bi[q], V);
+#pragma unroll
+        for (int q = 0; q < kTtaPts; ++q) {
             const int i = i0 + q * kTtaThreads;
             if (i >= N) continue;
-            const f32x4 h = hv[p[q].bi], n = hn[p[q].bi];
-            const float dot = (h[0] - p[q].x) * n[0] + (h[1] - p[q].y) * n[1] + (h[2] - p[q].z) * n[2];
-            const long long fx = __float2ll_rn(p[q].x * kFix), fy = __float2ll_rn(p[q].y * kFix), fz = __float2ll_rn(p[q].z * kFix);
+            const float ox = px[q >> 1][q & 1], oy = py[q >> 1][q & 1], oz = pz[q >> 1][q & 1], bd = best[q >> 1][q & 1];
+            const f32x4 h = hv[bi[q]], n = hn[bi[q]];
+            const float dot = (h[0] - ox) * n[0] + (h[1] - oy) * n[1] + (h[2] - oz) * n[2];
+            const long long fx = __float2ll_rn(ox * kFix), fy = __float2ll_rn(oy * kFix), fz = __float2ll_rn(oz * kFix);
             if (dot > 0.f) {
-                pen += p[q].best;
-                atomicAdd(&cntP[p[q].bi], 1);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&sumP[3 * p[q].bi + 0]), (unsigned long long)fx);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&sumP[3 * p[q].bi + 1]), (unsigned long long)fy);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&sumP[3 * p[q].bi + 2]), (unsigned long long)fz);
+                pen += bd;
+                atomicAdd(&cntP[bi[q]], 1);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&sumP[3 * bi[q] + 0]), (unsigned long long)fx);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&sumP[3 * bi[q] + 1]), (unsigned long long)fy);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&sumP[3 * bi[q] + 2]), (unsigned long long)fz);
             }
-            if (p[q].best < thresh) {
+            if (bd < thresh) {
                 ++ncon;
-                con += p[q].cbest;
-                atomicAdd(&cntC[p[q].ci], 1);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&sumC[3 * p[q].ci + 0]), (unsigned long long)fx);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&sumC[3 * p[q].ci + 1]), (unsigned long long)fy);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&sumC[3 * p[q].ci + 2]), (unsigned long long)fz);
+                con += cbest[q];
+                atomicAdd(&cntC[ci[q]], 1);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&sumC[3 * ci[q] + 0]), (unsigned long long)fx);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&sumC[3 * ci[q] + 1]), (unsigned long long)fy);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&sumC[3 * ci[q] + 2]), (unsigned long long)fz);
             }
-            if (nn_idx) nn_idx[(int64_t)b * N + i] = p[q].bi;
+            if (nn_idx) nn_idx[(int64_t)b * N + i] = __float_as_int(h[3]);
         }
     }
     pen = wave_sum(pen); con = wave_sum(con); ncon = wave_sum_i(ncon);
@@ -147,14 +193,15 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
         losses[2 * b + 1] = nT > 0 ? contact_scale * conT / (float)nT : 0.f;
     }
     float* gb = grad_verts + (int64_t)b * V * 3;
-    for (int v = tid; v < V; v += kTtaThreads) {
-        const f32x4 h = hv[v];
-        const int nP = cntP[v], nC = cntC[v];
+    for (int k = tid; k < V; k += kTtaThreads) {
+        const f32x4 h = hv[k];
+        const int v = __float_as_int(h[3]);
+        const int nP = cntP[k], nC2 = cntC[k];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const long long fv = __float2ll_rn(h[c] * kFix);
-            const float dP = (float)(fv * nP - sumP[3 * v + c]) * kUnfix;     // sum of (v - o_i), penetrating points
-            const float dC = (float)(fv * nC - sumC[3 * v + c]) * kUnfix;     // same, contact points
+            const float dP = (float)(fv * nP - sumP[3 * k + c]) * kUnfix;     // sum of (v - o_i), penetrating points
+            const float dC = (float)(fv * nC2 - sumC[3 * k + c]) * kUnfix;    // same, contact points
             gb[3 * v + c] = cP * dP + cC * dC;
         }
     }
@@ -448,17 +495,18 @@ extern "C" int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, 
     if (!obj || !verts || !mesh || !grad_verts || !losses) return fail(DVQ_EINVAL, "tta_contact_grad: null pointer");
     if (n_points < 1 || n_points > (1 << 20)) return fail(DVQ_EINVAL, "tta_contact_grad: n_points out of range (%d)", n_points);
     if (mesh->n_verts < 1 || mesh->n_verts > 1500) return fail(DVQ_EINVAL, "tta_contact_grad: 1..1500 hand vertices (got %d)", mesh->n_verts);
-    if (mesh->n_faces < 0 || !mesh->faces || !mesh->vert_face_ptr || !mesh->vert_face || !mesh->contact_mask)
+    if (mesh->n_faces < 0 || !mesh->faces || !mesh->vert_face_ptr || !mesh->vert_face || !mesh->search_order)
         return fail(DVQ_EINVAL, "tta_contact_grad: incomplete hand mesh");
-    const size_t lds = (size_t)mesh->n_verts * (16 + 16 + 24 + 24 + 4 + 4);
+    if (mesh->n_contact < 1 || mesh->n_contact > mesh->n_verts) return fail(DVQ_EINVAL, "tta_contact_grad: empty contact set");
+    const size_t lds = (size_t)mesh->n_verts * (16 + 16 + 24 + 24 + 4 + 4 + 4);
     if (lds > 150 * 1024) return fail(DVQ_EINVAL, "tta_contact_grad: hand mesh too large for LDS");
     // the kernel also holds a few hundred bytes of static LDS, so ask for what is needed, not for the whole array
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(tta_contact_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return fail(DVQ_ELAUNCH, "tta_contact_grad: cannot raise the dynamic LDS limit to %zu bytes", lds);
     hipLaunchKernelGGL(tta_contact_grad_kernel, dim3(B), dim3(kTtaThreads), lds, as_stream(stream), obj, obj_batch_stride,
-                       obj_chan_stride, obj_point_stride, n_points, verts, mesh->n_verts, mesh->faces, mesh->vert_face_ptr,
-                       mesh->vert_face, mesh->contact_mask, contact_dist_sq, penetr_scale, contact_scale, w_penetr, w_contact,
+                       obj_chan_stride, obj_point_stride, n_points, verts, mesh->n_verts, mesh->n_contact, mesh->faces, mesh->vert_face_ptr,
+                       mesh->vert_face, mesh->search_order, contact_dist_sq, penetr_scale, contact_scale, w_penetr, w_contact,
                        grad_verts, losses, nn_idx);
     return check_launch("tta_contact_grad");
 }

@@ -29,8 +29,8 @@ class DvqManoConsts(ctypes.Structure):
 
 
 class DvqHandMesh(ctypes.Structure):
-    _fields_ = [("n_verts", c_int), ("n_faces", c_int), ("faces", c_void_p), ("vert_face_ptr", c_void_p),
-                ("vert_face", c_void_p), ("contact_mask", c_void_p)]
+    _fields_ = [("n_verts", c_int), ("n_faces", c_int), ("n_contact", c_int), ("faces", c_void_p), ("vert_face_ptr", c_void_p),
+                ("vert_face", c_void_p), ("search_order", c_void_p)]
 
 
 class DvqPriorTap(ctypes.Structure):

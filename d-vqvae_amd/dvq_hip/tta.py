@@ -36,7 +36,7 @@ W_PENETR, W_CONTACT = 5.0, 1.0  # gen_HDMO_TTA.py:150
 
 def hand_mesh(faces, n_verts: int, contact_verts: Sequence[int], device):
     """Device tables of a hand mesh for ops.tta_contact_grad: faces [F,3], the faces incident to
-    each vertex (CSR) and the contact-set mask.  Returns (DvqHandMesh, tensors to keep alive)."""
+    each vertex (CSR) and the search order (contact set first).  Returns (DvqHandMesh, tensors to keep alive)."""
     f = np.asarray(faces.detach().cpu().numpy() if torch.is_tensor(faces) else faces, dtype=np.int64).reshape(-1, 3)
     if f.size and (f.min() < 0 or f.max() >= n_verts):
         raise ValueError("face index outside the vertex range")
@@ -46,20 +46,20 @@ def hand_mesh(faces, n_verts: int, contact_verts: Sequence[int], device):
     ptr = np.zeros(n_verts + 1, dtype=np.int64)
     np.add.at(ptr, vert + 1, 1)
     ptr = np.cumsum(ptr)
-    mask = np.zeros(n_verts, dtype=np.uint8)
-    cv = np.asarray(list(contact_verts), dtype=np.int64)
+    cv = np.unique(np.asarray(list(contact_verts), dtype=np.int64))
     if cv.size == 0 or cv.min() < 0 or cv.max() >= n_verts:
         raise ValueError("the contact set must name at least one vertex of the mesh")
-    mask[cv] = 1
+    rest = np.setdiff1d(np.arange(n_verts), cv)
+    search_order = np.concatenate([cv, rest])          # contact set first, each group ascending
     keep = dict(faces=torch.tensor(f, dtype=torch.int32, device=device).contiguous(),
                 ptr=torch.tensor(ptr, dtype=torch.int32, device=device),
                 vf=torch.tensor(face[order], dtype=torch.int32, device=device),
-                mask=torch.tensor(mask, dtype=torch.uint8, device=device))
+                order=torch.tensor(search_order, dtype=torch.int32, device=device))
     if keep["vf"].numel() == 0:
         keep["vf"] = torch.zeros(1, dtype=torch.int32, device=device)
         keep["faces"] = torch.zeros(1, 3, dtype=torch.int32, device=device)
-    mesh = DvqHandMesh(int(n_verts), int(f.shape[0]), keep["faces"].data_ptr(), keep["ptr"].data_ptr(),
-                       keep["vf"].data_ptr(), keep["mask"].data_ptr())
+    mesh = DvqHandMesh(int(n_verts), int(f.shape[0]), int(cv.size), keep["faces"].data_ptr(), keep["ptr"].data_ptr(),
+                       keep["vf"].data_ptr(), keep["order"].data_ptr())
     return mesh, keep
 
 

@@ -170,10 +170,12 @@ int dvq_mano_lbs_backward(const float* global_orient, const float* hand_pose, in
 typedef struct {
     int n_verts;
     int n_faces;
-    const int* faces;                  /* [F,3]                                            */
-    const int* vert_face_ptr;          /* [V+1] offsets into vert_face                     */
-    const int* vert_face;              /* faces incident to each vertex, grouped by vertex */
-    const unsigned char* contact_mask; /* [V] 1 = vertex belongs to the contact set        */
+    int n_contact;                     /* size of the contact set (>= 1)                                  */
+    const int* faces;                  /* [F,3]                                                           */
+    const int* vert_face_ptr;          /* [V+1] offsets into vert_face                                    */
+    const int* vert_face;              /* faces incident to each vertex, grouped by vertex                */
+    const int* search_order;           /* [V] all vertex ids, the n_contact contact-set vertices first;   */
+                                       /* equal distances resolve to the vertex that comes first here     */
 } DvqHandMesh;
 
 int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, int64_t obj_chan_stride, int64_t obj_point_stride,

@@ -98,6 +98,26 @@ def prior():
             print(f"prior.generate B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  ({1.22e9 * B / ms / 1e9:7.1f} TFLOP/s useful)", flush=True)
 
 
+def tta():
+    import mano as M
+    from dvq_hip.mano_io import Struct
+    from dvq_hip.tta import GraspRefiner
+    rh = M.MANO('', data_struct=Struct(**synth.mano_model_data(0)), use_pca=True, num_pca_comps=45, batch_size=1,
+                flat_hand_mean=True).to(dev).eval()
+    for B in (4096, 256, 1):
+        go, hp, tr = (t.to(dev) for t in synth.mano_inputs(B, seed=1))
+        param = torch.zeros(B, 61, device=dev)
+        param[:, 10:13], param[:, 13:58], param[:, 58:] = go, hp, tr
+        verts = rh(global_orient=go, hand_pose=hp, transl=tr).vertices
+        obj = verts.mean(1, keepdim=True) + 0.04 * torch.randn(B, 3000, 3, device=dev)
+        obj_pc = torch.cat([obj.permute(0, 2, 1), torch.full((B, 1, 3000), 0.2, device=dev)], 1).contiguous()
+        r = GraspRefiner(rh)
+        iters = 50
+        ms = timeit(lambda: r.refine(obj_pc, param, iters=iters), iters=2, warm=1)
+        print(f"tta refine B={B}: {ms / iters:8.4f} ms/iteration  {B * iters / ms * 1e3:10.0f} grasp-iterations/s  "
+              f"(300 iterations: {ms / iters * 300:8.1f} ms per batch)", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pointnet", "vq", "mano", "linear"]
     for w in which:
