@@ -11,7 +11,7 @@
 //    result independent of the order the points arrive in.
 //  * mano_lbs_backward_kernel -- the vector-Jacobian product of the MANO layer
 //    (DVQ-VAE-2/MANO-master/mano/lbs.py:33-265 differentiated by hand): skinning -> pose blend
-//    shapes -> kinematic chain -> Rodrigues -> PCA, one workgroup per hand.
+//    shapes -> kinematic chain -> Rodrigues -> PCA, four hands per workgroup.
 #include "common.h"
 
 namespace dvq {
@@ -34,12 +34,16 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kTtaPts = 4;   // object points per thread and pass (two packed-fp32 pairs)
+// 768 threads x 4 points cover a 3000-point cloud in one pass, and twelve waves per workgroup (two workgroups
+// per CU) give each SIMD six waves to hide the LDS latency of the vertex reads behind other waves' arithmetic.
+constexpr int kCgThreads = 768;
+constexpr int kCgWaves = kCgThreads / 64;
 
 // Vertices are searched in `order`: the n_contact vertices of the contact set first, then the others.
 // The nearest contact-set vertex is then simply the running minimum at the end of the first group, and
 // every (point, vertex) pair costs three packed subtract/multiply-add pairs and one compare-select, not two.
 // Exact distance ties resolve to the vertex met first in that order.
-__global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
+__global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
     const float* __restrict__ obj, int64_t sb, int64_t sc, int64_t sp, int N, const float* __restrict__ verts, int V, int nC,
     const int* __restrict__ faces, const int* __restrict__ vf_ptr, const int* __restrict__ vf,
     const int* __restrict__ order, float thresh, float penetr_scale, float contact_scale, float w_penetr,
@@ -52,15 +56,15 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
     int* cntP = reinterpret_cast<int*>(sumC + 3 * V);
     int* cntC = cntP + V;
     int* rank = cntC + V;                                                // vertex id -> k
-    __shared__ float sPen[kTtaWaves], sCon[kTtaWaves];
-    __shared__ int sN[kTtaWaves];
+    __shared__ float sPen[kCgWaves], sCon[kCgWaves];
+    __shared__ int sN[kCgWaves];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const float* vb = verts + (int64_t)b * V * 3;
     const float inf = __builtin_inff();
 
-    for (int k = tid; k < V; k += kTtaThreads) {
+    for (int k = tid; k < V; k += kCgThreads) {
         const int v = order[k];
         f32x4 h;
         h[0] = vb[3 * v]; h[1] = vb[3 * v + 1]; h[2] = vb[3 * v + 2];
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
     }
     __syncthreads();
     // vertex normals: sum of (p1 - p0) x (p2 - p0) over the incident faces
-    for (int k = tid; k < V; k += kTtaThreads) {
+    for (int k = tid; k < V; k += kCgThreads) {
         const int v = order[k];
         float nx = 0.f, ny = 0.f, nz = 0.f;
         for (int q = vf_ptr[v]; q < vf_ptr[v + 1]; ++q) {
@@ -93,12 +97,12 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
     float pen = 0.f, con = 0.f;
     int ncon = 0;
     const float* ob = obj + (int64_t)b * sb;
-    for (int i0 = tid; i0 < N; i0 += kTtaPts * kTtaThreads) {
+    for (int i0 = tid; i0 < N; i0 += kTtaPts * kCgThreads) {
         f32x2 px[2], py[2], pz[2], best[2];
         int bi[kTtaPts];
 #pragma unroll
         for (int q = 0; q < kTtaPts; ++q) {
-            int i = i0 + q * kTtaThreads;
+            int i = i0 + q * kCgThreads;
             if (i >= N) i = i0;
             px[q >> 1][q & 1] = ob[i * sp]; py[q >> 1][q & 1] = ob[sc + i * sp]; pz[q >> 1][q & 1] = ob[2 * sc + i * sp];
             best[q >> 1][q & 1] = inf;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
         for (int q = 0; q < kTtaPts; ++q) bi[q] = bi[q] < 0 ? exact[q] : resolve(q, bi[q], V);
 #pragma unroll
         for (int q = 0; q < kTtaPts; ++q) {
-            const int i = i0 + q * kTtaThreads;
+            const int i = i0 + q * kCgThreads;
             if (i >= N) continue;
             const float ox = px[q >> 1][q & 1], oy = py[q >> 1][q & 1], oz = pz[q >> 1][q & 1], bd = best[q >> 1][q & 1];
             const f32x4 h = hv[bi[q]], n = hn[bi[q]];
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
     float penT = 0.f, conT = 0.f;
     int nT = 0;
 #pragma unroll
-    for (int w = 0; w < kTtaWaves; ++w) { penT += sPen[w]; conT += sCon[w]; nT += sN[w]; }
+    for (int w = 0; w < kCgWaves; ++w) { penT += sPen[w]; conT += sCon[w]; nT += sN[w]; }
     const float cP = 2.f * w_penetr * penetr_scale;
     const float cC = nT > 0 ? 2.f * w_contact * contact_scale / (float)nT : 0.f;
     if (tid == 0) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
         losses[2 * b + 1] = nT > 0 ? contact_scale * conT / (float)nT : 0.f;
     }
     float* gb = grad_verts + (int64_t)b * V * 3;
-    for (int k = tid; k < V; k += kTtaThreads) {
+    for (int k = tid; k < V; k += kCgThreads) {
         const f32x4 h = hv[k];
         const int v = __float_as_int(h[3]);
         const int nP = cntP[k], nC2 = cntC[k];
@@ -210,35 +214,43 @@ __global__ __launch_bounds__(kTtaThreads) void tta_contact_grad_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kBwJ = 16;
 constexpr int kBwPF = 135;
+constexpr int kBwHB = 4;        // hands per workgroup: every posedirs element fetched feeds kBwHB multiply-adds
+constexpr int kBwSlices = kTtaThreads / kBwJ;   // vertex slices of the dL/dA reduction
 
-__global__ __launch_bounds__(kTtaThreads) void mano_lbs_backward_kernel(
+struct BwShared {
+    float Rv[kBwHB][kBwJ][3];      // full pose (axis-angle per joint)
+    float R[kBwHB][kBwJ][9];
+    float T[kBwHB][kBwJ][12];      // world transforms
+    float A[kBwHB][kBwJ][12];      // skinning transforms
+    float dA[kBwHB][kBwJ][12];
+    float dPF[kBwHB][kBwPF + 1];
+    float dGR[kBwHB][kBwJ][9];
+    float dGt[kBwHB][kBwJ][3];
+    float dR[kBwHB][kBwJ][9];
+    float dPose[kBwHB][48];
+    float Tr[kBwHB][kTtaWaves][3];
+};
+
+__global__ __launch_bounds__(kTtaThreads, 2) void mano_lbs_backward_kernel(
     const float* __restrict__ global_orient, const float* __restrict__ hand_pose, int B, int V, int ncomp,
     const float* __restrict__ joints, const float* __restrict__ posedirs, const float* __restrict__ weights,
     const float* __restrict__ comps, const float* __restrict__ pose_mean, const int* __restrict__ parents,
     const float* __restrict__ v_posed, const float* __restrict__ grad_verts, float* __restrict__ g_orient,
     float* __restrict__ g_pose, float* __restrict__ g_transl) {
     extern __shared__ __attribute__((aligned(16))) char bw_smem[];
-    float* sG = reinterpret_cast<float*>(bw_smem);     // [3V] dL/dverts of this hand
-    float* sVP = sG + 3 * V;                           // [3V] v_posed
-    float* sDVP = sVP + 3 * V;                         // [3V] dL/dv_posed
-    __shared__ float sRv[kBwJ][3];      // full pose (axis-angle per joint)
-    __shared__ float sR[kBwJ][9];
-    __shared__ float sT[kBwJ][12];      // world transforms
-    __shared__ float sA[kBwJ][12];      // skinning transforms
-    __shared__ float sdA[kBwJ][12];
-    __shared__ float sdPF[kBwPF + 1];
-    __shared__ float sdGR[kBwJ][9];
-    __shared__ float sdGt[kBwJ][3];
-    __shared__ float sdR[kBwJ][9];
-    __shared__ float sdPose[48];
-    __shared__ float sTr[kTtaWaves][3];
+    // [kBwHB][3V] dL/dv_posed; before it is filled the same memory holds the per-wave partial sums of dL/dA
+    float* sDVP = reinterpret_cast<float*>(bw_smem);
+    float* sPart = sDVP;                                  // [kBwHB][waves][16][12]
+    __shared__ BwShared sh;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int b0 = blockIdx.x * kBwHB;
+    const int nh = (B - b0) < kBwHB ? (B - b0) : kBwHB;
+    const int V3 = 3 * V;
 
-    // forward pieces needed again: full pose, rotations   (lbs.py:167-198)
-    if (tid < kBwJ) {
-        const int j = tid;
+    // ---- forward pieces needed again: full pose, rotations   (lbs.py:167-198)
+    if (tid < kBwHB * kBwJ && tid / kBwJ < nh) {
+        const int h = tid / kBwJ, j = tid % kBwJ, b = b0 + h;
         float rv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(kTtaThreads) void mano_lbs_backward_kernel(
             }
             v += pose_mean[3 * j + c];
             rv[c] = v;
-            sRv[j][c] = v;
+            sh.Rv[h][j][c] = v;
         }
         const float ax = rv[0] + 1e-8f, ay = rv[1] + 1e-8f, az = rv[2] + 1e-8f;
         const float angle = sqrtf(ax * ax + ay * ay + az * az);
@@ -267,16 +279,13 @@ __global__ __launch_bounds__(kTtaThreads) void mano_lbs_backward_kernel(
                 float kk = K[a * 3 + 0] * K[0 * 3 + c];
                 kk = __builtin_fmaf(K[a * 3 + 1], K[1 * 3 + c], kk);
                 kk = __builtin_fmaf(K[a * 3 + 2], K[2 * 3 + c], kk);
-                sR[j][a * 3 + c] = ((a == c ? 1.f : 0.f) + sn * K[a * 3 + c]) + omc * kk;
+                sh.R[h][j][a * 3 + c] = ((a == c ? 1.f : 0.f) + sn * K[a * 3 + c]) + omc * kk;
             }
     }
-    for (int e = tid; e < 3 * V; e += kTtaThreads) {
-        sG[e] = grad_verts[(int64_t)b * 3 * V + e];
-        sVP[e] = v_posed[(int64_t)b * 3 * V + e];
-    }
     __syncthreads();
-    // kinematic chain   (lbs.py:214-265)
-    if (tid == 0) {
+    // ---- kinematic chain, one thread per hand   (lbs.py:214-265)
+    if (tid < nh) {
+        const int h = tid;
         for (int i = 0; i < kBwJ; ++i) {
             const int par = parents[i];
             float t[3];
@@ -287,18 +296,18 @@ __global__ __launch_bounds__(kTtaThreads) void mano_lbs_backward_kernel(
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) T[a * 4 + c] = sR[0][a * 3 + c];
+                    for (int c = 0; c < 3; ++c) T[a * 4 + c] = sh.R[h][0][a * 3 + c];
                     T[a * 4 + 3] = t[a];
                 }
             } else {
-                const float* P = sT[par];
+                const float* P = sh.T[h][par];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        float v = P[a * 4 + 0] * sR[i][0 * 3 + c];
-                        v = __builtin_fmaf(P[a * 4 + 1], sR[i][1 * 3 + c], v);
-                        v = __builtin_fmaf(P[a * 4 + 2], sR[i][2 * 3 + c], v);
+                        float v = P[a * 4 + 0] * sh.R[h][i][0 * 3 + c];
+                        v = __builtin_fmaf(P[a * 4 + 1], sh.R[h][i][1 * 3 + c], v);
+                        v = __builtin_fmaf(P[a * 4 + 2], sh.R[h][i][2 * 3 + c], v);
                         T[a * 4 + c] = v;
                     }
                     float v = P[a * 4 + 0] * t[0];
@@ -314,107 +323,164 @@ __global__ __launch_bounds__(kTtaThreads) void mano_lbs_backward_kernel(
                 v = __builtin_fmaf(T[a * 4 + 1], jy, v);
                 v = __builtin_fmaf(T[a * 4 + 2], jz, v);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) sT[i][a * 4 + c] = T[a * 4 + c];
-                sA[i][a * 4 + 0] = T[a * 4 + 0]; sA[i][a * 4 + 1] = T[a * 4 + 1]; sA[i][a * 4 + 2] = T[a * 4 + 2];
-                sA[i][a * 4 + 3] = T[a * 4 + 3] - v;
+                for (int c = 0; c < 4; ++c) sh.T[h][i][a * 4 + c] = T[a * 4 + c];
+                sh.A[h][i][a * 4 + 0] = T[a * 4 + 0]; sh.A[h][i][a * 4 + 1] = T[a * 4 + 1]; sh.A[h][i][a * 4 + 2] = T[a * 4 + 2];
+                sh.A[h][i][a * 4 + 3] = T[a * 4 + 3] - v;
+            }
+        }
+    }
+
+    // ---- dL/dA_j[a][k] = sum_v w_vj g_v[a] [v_posed_v; 1][k]: thread (joint, vertex slice), then slices are summed
+    {
+        const int j = tid & (kBwJ - 1), slice = tid >> 4;
+        const int per = (V + kBwSlices - 1) / kBwSlices;
+        const int v0 = slice * per, v1 = (v0 + per) < V ? (v0 + per) : V;
+#pragma unroll 1
+        for (int h = 0; h < nh; ++h) {
+            const float* g = grad_verts + (int64_t)(b0 + h) * V3;
+            const float* vp = v_posed + (int64_t)(b0 + h) * V3;
+            float acc[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+            for (int v = v0; v < v1; ++v) {
+                const float w = weights[v * kBwJ + j];
+                const float p0 = vp[3 * v], p1 = vp[3 * v + 1], p2 = vp[3 * v + 2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float wg = w * g[3 * v + a];
+                    acc[a * 4 + 0] = __builtin_fmaf(wg, p0, acc[a * 4 + 0]);
+                    acc[a * 4 + 1] = __builtin_fmaf(wg, p1, acc[a * 4 + 1]);
+                    acc[a * 4 + 2] = __builtin_fmaf(wg, p2, acc[a * 4 + 2]);
+                    acc[a * 4 + 3] += wg;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {       // the four slices that share a wave
+                float x = acc[e];
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                if (lane < kBwJ) sPart[((h * kTtaWaves + wave) * kBwJ + j) * 12 + e] = x;
             }
         }
     }
     __syncthreads();
-
-    // skinning backward, per vertex: verts = T_v [v_posed; 1] + transl, T_v = sum_j w_vj A_j
-    float tr[3] = {0.f, 0.f, 0.f};
-    for (int v = tid; v < V; v += kTtaThreads) {
-        float TR[9];
+    for (int o = tid; o < nh * kBwJ * 12; o += kTtaThreads) {
+        const int h = o / (kBwJ * 12), r = o % (kBwJ * 12);
+        float x = 0.f;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) TR[e] = 0.f;
-#pragma unroll
-        for (int j = 0; j < kBwJ; ++j) {
-            const float w = weights[v * kBwJ + j];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) TR[a * 3 + c] = __builtin_fmaf(w, sA[j][a * 4 + c], TR[a * 3 + c]);
-        }
-        const float g0 = sG[3 * v], g1 = sG[3 * v + 1], g2 = sG[3 * v + 2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) sDVP[3 * v + c] = TR[0 * 3 + c] * g0 + TR[1 * 3 + c] * g1 + TR[2 * 3 + c] * g2;
-        tr[0] += g0; tr[1] += g1; tr[2] += g2;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float s = wave_sum(tr[c]);
-        if (lane == 0) sTr[wave][c] = s;
+        for (int w = 0; w < kTtaWaves; ++w) x += sPart[(h * kTtaWaves + w) * kBwJ * 12 + r];
+        sh.dA[h][r / 12][r % 12] = x;
     }
     __syncthreads();
 
-    // dL/dA_j[a][k] = sum_v w_vj g_v[a] [v_posed_v; 1][k]
-    if (tid < kBwJ * 12) {
-        const int j = tid / 12, a = (tid % 12) / 4, k = tid % 4;
-        float acc = 0.f;
-        if (k < 3) {
-            for (int v = 0; v < V; ++v) acc = __builtin_fmaf(weights[v * kBwJ + j] * sG[3 * v + a], sVP[3 * v + k], acc);
-        } else {
-            for (int v = 0; v < V; ++v) acc = __builtin_fmaf(weights[v * kBwJ + j], sG[3 * v + a], acc);
+    // ---- skinning backward, per vertex: verts = T_v [v_posed; 1] + transl, T_v = sum_j w_vj A_j
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        for (int v = tid; v < V; v += kTtaThreads) {
+            float TR[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) TR[e] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(weights + v * kBwJ + 4 * q);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            TR[a * 3 + c] = __builtin_fmaf(w[jj], sh.A[h][4 * q + jj][a * 4 + c], TR[a * 3 + c]);
+            }
+            const float* g = grad_verts + ((int64_t)(b0 + h) * V + v) * 3;
+            const float g0 = g[0], g1 = g[1], g2 = g[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sDVP[h * V3 + 3 * v + c] = TR[0 * 3 + c] * g0 + TR[1 * 3 + c] * g1 + TR[2 * 3 + c] * g2;
+            t0 += g0; t1 += g1; t2 += g2;
         }
-        sdA[j][a * 4 + k] = acc;
-    }
-    // dL/dpose_feature[p] = sum_e posedirs[p][e] dv_posed[e]   (lbs.py:99-101)
-    for (int p = wave; p < kBwPF; p += kTtaWaves) {
-        const float* pd = posedirs + (int64_t)p * 3 * V;
-        float acc = 0.f;
-        for (int e = lane; e < 3 * V; e += 64) acc = __builtin_fmaf(pd[e], sDVP[e], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) sdPF[p] = acc;
+        t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+        if (lane == 0) { sh.Tr[h][wave][0] = t0; sh.Tr[h][wave][1] = t1; sh.Tr[h][wave][2] = t2; }
     }
     __syncthreads();
 
-    // chain backward (children have larger indices than their parents)
-    if (tid == 0) {
+    // ---- dL/dpose_feature[p] = sum_e posedirs[p][e] dv_posed[e]   (lbs.py:99-101), four p per wave and pass
+    for (int p0 = 4 * wave; p0 < kBwPF; p0 += 4 * kTtaWaves) {
+        float acc[4][kBwHB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < kBwHB; ++h) acc[u][h] = 0.f;
+        const float* pd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pd[u] = posedirs + (int64_t)((p0 + u) < kBwPF ? (p0 + u) : (kBwPF - 1)) * V3;
+        for (int e = lane; e < V3; e += 64) {
+            float d[kBwHB];
+#pragma unroll
+            for (int h = 0; h < kBwHB; ++h) d[h] = h < nh ? sDVP[h * V3 + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x = pd[u][e];
+#pragma unroll
+                for (int h = 0; h < kBwHB; ++h) acc[u][h] = __builtin_fmaf(x, d[h], acc[u][h]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < kBwHB; ++h) {
+                const float x = wave_sum(acc[u][h]);
+                if (lane == 0 && p0 + u < kBwPF) sh.dPF[h][p0 + u] = x;
+            }
+    }
+    __syncthreads();
+
+    // ---- chain backward, one thread per hand (children have larger indices than their parents)
+    if (tid < nh) {
+        const int h = tid;
         for (int j = 0; j < kBwJ; ++j) {
             const float jx = joints[j * 3], jy = joints[j * 3 + 1], jz = joints[j * 3 + 2];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {   // A = [G_R | G_t - G_R J]
-                const float dt = sdA[j][a * 4 + 3];
-                sdGR[j][a * 3 + 0] = sdA[j][a * 4 + 0] - dt * jx;
-                sdGR[j][a * 3 + 1] = sdA[j][a * 4 + 1] - dt * jy;
-                sdGR[j][a * 3 + 2] = sdA[j][a * 4 + 2] - dt * jz;
-                sdGt[j][a] = dt;
+                const float dt = sh.dA[h][j][a * 4 + 3];
+                sh.dGR[h][j][a * 3 + 0] = sh.dA[h][j][a * 4 + 0] - dt * jx;
+                sh.dGR[h][j][a * 3 + 1] = sh.dA[h][j][a * 4 + 1] - dt * jy;
+                sh.dGR[h][j][a * 3 + 2] = sh.dA[h][j][a * 4 + 2] - dt * jz;
+                sh.dGt[h][j][a] = dt;
             }
         }
         for (int i = kBwJ - 1; i >= 1; --i) {
             const int par = parents[i];
-            const float* P = sT[par];
+            const float* P = sh.T[h][par];
             float rel[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) rel[c] = joints[i * 3 + c] - joints[par * 3 + c];
             float dGR[9], dGt[3];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) dGR[e] = sdGR[i][e];
+            for (int e = 0; e < 9; ++e) dGR[e] = sh.dGR[h][i][e];
 #pragma unroll
-            for (int e = 0; e < 3; ++e) dGt[e] = sdGt[i][e];
+            for (int e = 0; e < 3; ++e) dGt[e] = sh.dGt[h][i][e];
             // G_R,i = G_R,par R_i ; G_t,i = G_R,par rel_i + G_t,par
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float dR = P[0 * 4 + a] * dGR[0 * 3 + c] + P[1 * 4 + a] * dGR[1 * 3 + c] + P[2 * 4 + a] * dGR[2 * 3 + c];
-                    sdR[i][a * 3 + c] = dR + sdPF[(i - 1) * 9 + a * 3 + c];
-                    sdGR[par][a * 3 + c] += dGR[a * 3 + 0] * sR[i][c * 3 + 0] + dGR[a * 3 + 1] * sR[i][c * 3 + 1] +
-                                            dGR[a * 3 + 2] * sR[i][c * 3 + 2] + dGt[a] * rel[c];
+                    sh.dR[h][i][a * 3 + c] = dR + sh.dPF[h][(i - 1) * 9 + a * 3 + c];
+                    sh.dGR[h][par][a * 3 + c] += dGR[a * 3 + 0] * sh.R[h][i][c * 3 + 0] + dGR[a * 3 + 1] * sh.R[h][i][c * 3 + 1] +
+                                                 dGR[a * 3 + 2] * sh.R[h][i][c * 3 + 2] + dGt[a] * rel[c];
                 }
 #pragma unroll
-            for (int a = 0; a < 3; ++a) sdGt[par][a] += dGt[a];
+            for (int a = 0; a < 3; ++a) sh.dGt[h][par][a] += dGt[a];
         }
 #pragma unroll
-        for (int e = 0; e < 9; ++e) sdR[0][e] = sdGR[0][e];
+        for (int e = 0; e < 9; ++e) sh.dR[h][0][e] = sh.dGR[h][0][e];
     }
     __syncthreads();
 
-    // Rodrigues backward, one thread per joint
-    if (tid < kBwJ) {
-        const int j = tid;
-        const float vx = sRv[j][0], vy = sRv[j][1], vz = sRv[j][2];
+    // ---- Rodrigues backward, one thread per (hand, joint)
+    if (tid < kBwHB * kBwJ && tid / kBwJ < nh) {
+        const int h = tid / kBwJ, j = tid % kBwJ;
+        const float vx = sh.Rv[h][j][0], vy = sh.Rv[h][j][1], vz = sh.Rv[h][j][2];
         const float ex = vx + 1e-8f, ey = vy + 1e-8f, ez = vz + 1e-8f;
         const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
         const float inv = 1.f / ang;
@@ -427,7 +493,7 @@ __global__ __launch_bounds__(kTtaThreads) void mano_lbs_backward_kernel(
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 KK[a * 3 + c] = K[a * 3 + 0] * K[0 * 3 + c] + K[a * 3 + 1] * K[1 * 3 + c] + K[a * 3 + 2] * K[2 * 3 + c];
-                dR[a * 3 + c] = sdR[j][a * 3 + c];
+                dR[a * 3 + c] = sh.dR[h][j][a * 3 + c];
             }
         float dS = 0.f, dO = 0.f;
 #pragma unroll
@@ -447,21 +513,24 @@ __global__ __launch_bounds__(kTtaThreads) void mano_lbs_backward_kernel(
         const float dnz = dK[1 * 3 + 0] - dK[0 * 3 + 1];
         float da = cs * dS + sn * dO;
         da -= (dnx * vx + dny * vy + dnz * vz) * inv * inv;
-        sdPose[3 * j + 0] = dnx * inv + da * ex * inv;
-        sdPose[3 * j + 1] = dny * inv + da * ey * inv;
-        sdPose[3 * j + 2] = dnz * inv + da * ez * inv;
+        sh.dPose[h][3 * j + 0] = dnx * inv + da * ex * inv;
+        sh.dPose[h][3 * j + 1] = dny * inv + da * ey * inv;
+        sh.dPose[h][3 * j + 2] = dnz * inv + da * ez * inv;
     }
     __syncthreads();
 
-    if (tid < 3) {
-        if (g_orient) g_orient[b * 3 + tid] = sdPose[tid];
-        if (g_transl) g_transl[b * 3 + tid] = ((sTr[0][tid] + sTr[1][tid]) + sTr[2][tid]) + sTr[3][tid];
+    if (tid < nh * 3) {
+        const int h = tid / 3, c = tid % 3, b = b0 + h;
+        if (g_orient) g_orient[b * 3 + c] = sh.dPose[h][c];
+        if (g_transl) g_transl[b * 3 + c] = ((sh.Tr[h][0][c] + sh.Tr[h][1][c]) + sh.Tr[h][2][c]) + sh.Tr[h][3][c];
     }
-    if (g_pose && tid >= 64 && tid < 64 + ncomp) {   // pose = coefficients x components (model.py:330-331)
-        const int c = tid - 64;
-        float acc = 0.f;
-        for (int m = 0; m < 45; ++m) acc = __builtin_fmaf(comps[c * 45 + m], sdPose[3 + m], acc);
-        g_pose[b * ncomp + c] = acc;
+    if (g_pose) {   // pose = coefficients x components (model.py:330-331)
+        for (int o = tid; o < nh * ncomp; o += kTtaThreads) {
+            const int h = o / ncomp, c = o % ncomp;
+            float acc = 0.f;
+            for (int m = 0; m < 45; ++m) acc = __builtin_fmaf(comps[c * 45 + m], sh.dPose[h][3 + m], acc);
+            g_pose[(b0 + h) * ncomp + c] = acc;
+        }
     }
 }
 
@@ -475,12 +544,18 @@ extern "C" int dvq_mano_lbs_backward(const float* global_orient, const float* ha
     if (B < 0) return fail(DVQ_EINVAL, "mano_backward: negative batch");
     if (B == 0) return DVQ_OK;
     if (!m || !global_orient || !hand_pose || !v_posed || !grad_verts) return fail(DVQ_EINVAL, "mano_backward: null pointer");
-    if (m->n_verts < 1 || m->n_verts > 4096 || m->n_comps < 1 || m->n_comps > 45)
+    if (m->n_verts < 1 || m->n_verts > 2500 || m->n_comps < 1 || m->n_comps > 45)
         return fail(DVQ_EINVAL, "mano_backward: bad n_verts/n_comps (%d, %d)", m->n_verts, m->n_comps);
     if (!m->joints || !m->posedirs || !m->lbs_weights || !m->components || !m->pose_mean || !m->parents)
         return fail(DVQ_EINVAL, "mano_backward: null constant table");
-    const size_t lds = (size_t)9 * m->n_verts * sizeof(float);
-    hipLaunchKernelGGL(mano_lbs_backward_kernel, dim3(B), dim3(kTtaThreads), lds, as_stream(stream), global_orient, hand_pose, B,
+    if (((uintptr_t)m->lbs_weights & 15) != 0) return fail(DVQ_EINVAL, "mano_backward: lbs_weights must be 16-byte aligned");
+    size_t lds = (size_t)kBwHB * 3 * m->n_verts * sizeof(float);
+    const size_t part = (size_t)kBwHB * kTtaWaves * kBwJ * 12 * sizeof(float);
+    if (lds < part) lds = part;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mano_lbs_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return fail(DVQ_ELAUNCH, "mano_backward: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    hipLaunchKernelGGL(mano_lbs_backward_kernel, dim3((B + kBwHB - 1) / kBwHB), dim3(kTtaThreads), lds, as_stream(stream), global_orient, hand_pose, B,
                        m->n_verts, m->n_comps, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean, m->parents,
                        v_posed, grad_verts, grad_global_orient, grad_hand_pose, grad_transl);
     return check_launch("mano_lbs_backward");
@@ -504,7 +579,7 @@ extern "C" int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, 
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(tta_contact_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return fail(DVQ_ELAUNCH, "tta_contact_grad: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    hipLaunchKernelGGL(tta_contact_grad_kernel, dim3(B), dim3(kTtaThreads), lds, as_stream(stream), obj, obj_batch_stride,
+    hipLaunchKernelGGL(tta_contact_grad_kernel, dim3(B), dim3(kCgThreads), lds, as_stream(stream), obj, obj_batch_stride,
                        obj_chan_stride, obj_point_stride, n_points, verts, mesh->n_verts, mesh->n_contact, mesh->faces, mesh->vert_face_ptr,
                        mesh->vert_face, mesh->search_order, contact_dist_sq, penetr_scale, contact_scale, w_penetr, w_contact,
                        grad_verts, losses, nn_idx);
