@@ -25,6 +25,10 @@ int fail(int code, const char* fmt, ...);
 // Checks the launch that was just enqueued.
 int check_launch(const char* what);
 
+// Makes sure kernel `fn` may be launched with `bytes` of dynamic LDS on the current device (the runtime's
+// default ceiling is 64 KiB).  Remembers, per device and kernel, what has been granted; thread-safe.
+int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // round-to-nearest-even fp32 -> bf16 bits (NaN kept a NaN by the hardware convert)

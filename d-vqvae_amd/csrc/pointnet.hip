@@ -345,12 +345,7 @@ static size_t pn_lds_bytes() {
 template <int DT, int C>
 static int pn_launch(const float* x, const float* trans, int B, int N, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
     auto kern = pointnet_mlp_max_kernel<DT, C>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail(DVQ_ELAUNCH, "pointnet: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pn_lds_bytes<DT>(), "pointnet_mlp_max")) return rc;
     hipLaunchKernelGGL(kern, dim3(B), dim3(kPnThreads), pn_lds_bytes<DT>(), st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
                        reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat);
     return check_launch("pointnet_mlp_max");

@@ -28,9 +28,8 @@
 namespace dvq {
 
 constexpr int kPgWaves = 4;
-constexpr int kPgNO = 4;
-constexpr int kPgStageKB = 2;   // k-blocks (of 32 features) per LDS stage
-constexpr int kPgRing = 4;      // stage buffers
+constexpr int kPgStageKB = 1;   // k-blocks (of 32 features) per LDS stage
+constexpr int kPgRing = 3;      // stage buffers
 constexpr int kPgMaxTaps = 10;
 
 struct PgTapDev {
@@ -76,12 +75,16 @@ enum { PG_PACK = 0, PG_GATE = 1, PG_ROWS = 2 };
 //       half), y = group of 4 sample tiles (one per wave), z = job.  One workgroup per CU.
 //
 // Pipeline: every operand byte reaches LDS by direct global->LDS loads (no register-destination
-// load inside the loop), in stages of KS=2 k-blocks (weights NO x 4 KiB shared by the four waves,
-// activations 4 KiB per wave) through a ring of R=4 stage buffers.  A wave waits only for ITS
-// loads of the stage it is about to read with a counted s_waitcnt vmcnt (two younger stages stay
-// in flight), then one s_barrier makes every wave's part visible and frees the buffer read two
-// stages ago, which is immediately refilled.  Products this small (M = 4096) are L2-latency
-// bound, not bandwidth bound: the depth of the ring is what buys throughput.
+// load inside the loop), in stages of KS k-blocks (weights NO x KS x 2 KiB shared by the four waves,
+// activations KS x 2 KiB per wave) through a ring of R stage buffers.  A wave waits only for ITS
+// loads of the stage it is about to read with a counted s_waitcnt vmcnt (the younger stages stay
+// in flight), then one s_barrier makes every wave's part visible and frees the buffer read R-1
+// stages ago, which is immediately refilled.
+// A 128 x 128 output tile per workgroup is all a [4096 x 1024] product leaves for each of the 256
+// CUs, so every CU pulls 16 KiB through L2 per k-block of 32 features: the product is bound by
+// L2 -> LDS bandwidth (64 FLOP per byte), not by the matrix cores.  KS = 1 and R = 3 (48 KiB) keep
+// two loads in flight per wave, which is enough to saturate that path, and leave room in LDS for
+// workgroups of the point-cloud encoder that runs beside the prior on another stream.
 template <int EPI, int NO>
 __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -355,21 +358,14 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
     const dim3 grid(N / (32 * no), gy, n_jobs);
     const size_t lds = (size_t)kPgRing * (no * kPgStageKB * 2 + kPgWaves * kPgStageKB * 2) * 1024;
     hipStream_t st = as_stream(stream);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* fns[6] = {reinterpret_cast<const void*>(prior_gemm_kernel<PG_PACK, 2>), reinterpret_cast<const void*>(prior_gemm_kernel<PG_PACK, 4>),
-                              reinterpret_cast<const void*>(prior_gemm_kernel<PG_GATE, 2>), reinterpret_cast<const void*>(prior_gemm_kernel<PG_GATE, 4>),
-                              reinterpret_cast<const void*>(prior_gemm_kernel<PG_ROWS, 2>), reinterpret_cast<const void*>(prior_gemm_kernel<PG_ROWS, 4>)};
-        for (const void* f : fns)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return fail(DVQ_ELAUNCH, "prior_gemm: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
     const dim3 blk(kPgWaves * 64);
-#define DVQ_PG_LAUNCH(E)                                                                           \
-    do {                                                                                           \
-        if (no == 4) hipLaunchKernelGGL((prior_gemm_kernel<E, 4>), grid, blk, lds, st, dev, M, N, relu); \
-        else hipLaunchKernelGGL((prior_gemm_kernel<E, 2>), grid, blk, lds, st, dev, M, N, relu);        \
+#define DVQ_PG_LAUNCH(E)                                                                                            \
+    do {                                                                                                            \
+        const void* fn = no == 4 ? reinterpret_cast<const void*>(prior_gemm_kernel<E, 4>)                          \
+                                 : reinterpret_cast<const void*>(prior_gemm_kernel<E, 2>);                         \
+        if (int rc = ensure_dynamic_lds(fn, lds, "prior_gemm")) return rc;                                          \
+        if (no == 4) hipLaunchKernelGGL((prior_gemm_kernel<E, 4>), grid, blk, lds, st, dev, M, N, relu);           \
+        else hipLaunchKernelGGL((prior_gemm_kernel<E, 2>), grid, blk, lds, st, dev, M, N, relu);                   \
     } while (0)
     if (epilogue == PG_PACK) DVQ_PG_LAUNCH(PG_PACK);
     else if (epilogue == PG_GATE) DVQ_PG_LAUNCH(PG_GATE);

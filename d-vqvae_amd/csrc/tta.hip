@@ -552,9 +552,7 @@ extern "C" int dvq_mano_lbs_backward(const float* global_orient, const float* ha
     size_t lds = (size_t)kBwHB * 3 * m->n_verts * sizeof(float);
     const size_t part = (size_t)kBwHB * kTtaWaves * kBwJ * 12 * sizeof(float);
     if (lds < part) lds = part;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mano_lbs_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-        return fail(DVQ_ELAUNCH, "mano_backward: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mano_lbs_backward_kernel), lds, "mano_lbs_backward")) return rc;
     hipLaunchKernelGGL(mano_lbs_backward_kernel, dim3((B + kBwHB - 1) / kBwHB), dim3(kTtaThreads), lds, as_stream(stream), global_orient, hand_pose, B,
                        m->n_verts, m->n_comps, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean, m->parents,
                        v_posed, grad_verts, grad_global_orient, grad_hand_pose, grad_transl);
@@ -576,9 +574,7 @@ extern "C" int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, 
     const size_t lds = (size_t)mesh->n_verts * (16 + 16 + 24 + 24 + 4 + 4 + 4);
     if (lds > 150 * 1024) return fail(DVQ_EINVAL, "tta_contact_grad: hand mesh too large for LDS");
     // the kernel also holds a few hundred bytes of static LDS, so ask for what is needed, not for the whole array
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(tta_contact_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-        return fail(DVQ_ELAUNCH, "tta_contact_grad: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(tta_contact_grad_kernel), lds, "tta_contact_grad")) return rc;
     hipLaunchKernelGGL(tta_contact_grad_kernel, dim3(B), dim3(kCgThreads), lds, as_stream(stream), obj, obj_batch_stride,
                        obj_chan_stride, obj_point_stride, n_points, verts, mesh->n_verts, mesh->n_contact, mesh->faces, mesh->vert_face_ptr,
                        mesh->vert_face, mesh->search_order, contact_dist_sq, penetr_scale, contact_scale, w_penetr, w_contact,

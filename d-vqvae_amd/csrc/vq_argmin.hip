@@ -522,12 +522,7 @@ static int launch_reg(const void* z, const char* ws, const VqPlan& p, int64_t n,
     const int n_buf = n_stages > 1 ? 2 : 1;
     const size_t lds = (size_t)n_buf * TS * TILE_BYTES + (size_t)n_buf * TS * 32 * 4;
     auto kern = vq_argmin_reg_kernel<DT, D, NB, WAVES>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail(DVQ_ELAUNCH, "vq_argmin: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "vq_argmin")) return rc;
     const int64_t groups = (n + WAVES * NB * 32 - 1) / (WAVES * NB * 32);
     const int64_t max_blocks = (lds > 80 * 1024) ? kNumCU : 2 * kNumCU;
     const int grid = (int)(groups < max_blocks ? groups : max_blocks);
@@ -546,12 +541,7 @@ static int launch_bf16x(const void* z, const char* ws, const VqPlan& p, int64_t 
     const int n_stages = (p.n_tiles + TS - 1) / TS;
     const size_t lds = (size_t)(n_stages > 1 ? 2 : 1) * TS * TILE_BYTES;
     auto kern = vq_argmax_bf16_kernel<D, NB, WAVES>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail(DVQ_ELAUNCH, "vq_argmin: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "vq_argmin")) return rc;
     const int64_t groups = (n + WAVES * NB * 16 - 1) / (WAVES * NB * 16);
     const int64_t max_blocks = (lds > 80 * 1024) ? kNumCU : 2 * kNumCU;
     const int grid = (int)(groups < max_blocks ? groups : max_blocks);

@@ -89,7 +89,7 @@ def prior():
     model = GenNet()
     model.load_state_dict(synth.gennet_state_dict(0))
     pr = model.GatedPixelCNN.to(dev).eval()
-    for B in (4096, 512, 1):
+    for B in (4096, 2048, 512, 1):
         lab = torch.randint(0, 128, (B,), device=dev)
         u = rng.uniforms(torch.arange(B, device=dev), 9, 0)
         for dt in (torch.bfloat16, torch.float32):
