@@ -208,9 +208,15 @@ def main():
             avg_ms, launches, (kb, kc, kn), name = ks
             flops = float(kb) * kn * FLOP_PER_POINT[kc]
             ach = flops / avg_ms / 1e9
+            # HBM bytes per launch from the FETCH_SIZE (x2, the gfx950 correction for 16-B-per-lane streams) and
+            # WRITE_SIZE counters, collected in separate rocprofv3 --pmc passes of this workload
+            # (profiles/r1c_pmc_fetch_write.txt); only valid for the configuration it was measured on
+            traffic = 2.173e8 if (kb, kc, kn, args.dtype) == (4096, 4, 3000, "bf16") else None
             result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1),
                                   "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                                  "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
+                                  "traffic_note": "HBM bytes per launch, PMC passes in profiles/r1c_pmc_fetch_write.txt; "
+                                                  "algorithmic bytes 2.134e8",
                                   "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
                                   "flop_per_launch": flops}
 
