@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--prior", choices=["sampled", "forced"], default="sampled",
                     help="'forced' feeds given part indices instead of running the autoregressive prior")
+    ap.add_argument("--tta-iters", type=int, default=0,
+                    help="also refine every generated grasp with this many test-time-adaptation steps inside the timed step "
+                         "(the reference's adaptation script uses 300); default 0 = generation only")
     ap.add_argument("--no-extras", action="store_true", help="skip the VQ microbench, the variants and the CPU baseline")
     args = ap.parse_args()
 
@@ -174,10 +177,25 @@ def main():
     first_id = rank * B
     forced = torch.randint(0, 128, (B, 3, 3), device=device, generator=torch.Generator(device).manual_seed(rank))
 
+    refiner = None
+    if args.tta_iters > 0:
+        from dvq_hip.tta import GraspRefiner
+        refiner = GraspRefiner(gen.rh_mano, iters=args.tta_iters)
+
     def step(prior=args.prior):
-        out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None,
-                           gather=world > 1, n_total=world * B)
-        return out["vertices"]
+        if refiner is None:
+            out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None,
+                               gather=world > 1, n_total=world * B)
+            return out["vertices"]
+        # generation, then the adaptation loop on this rank's grasps, then the final hand and the gather
+        out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None)
+        p = refiner.refine(obj, out["recon_param"])["recon_param"]
+        verts = gen.rh_mano(global_orient=p[:, 10:13].contiguous(), hand_pose=p[:, 13:58].contiguous(),
+                            transl=p[:, 58:].contiguous()).vertices
+        if world > 1:
+            from dvq_hip import parallel
+            verts = parallel.gather_rows(verts, world * B)
+        return verts
 
     ops.enable_timers(True)
     elapsed = timed_steps(step, args.steps, args.warmup, device, barrier)
@@ -201,7 +219,7 @@ def main():
                                    "encoder -> pos decoder) + call-site MANO LBS" +
                                    (" + RCCL all-gather of vertices" if world > 1 else ""),
                        "objects_per_gpu": B, "points_per_object": N, "global_batch": world * B,
-                       "prior": args.prior, "weights": "random-init (seed 0), MANO-shaped synthetic hand model",
+                       "prior": args.prior, "tta_iterations": args.tta_iters, "weights": "random-init (seed 0), MANO-shaped synthetic hand model",
                        "parallelism": f"dp{world}"},
         }
         if ks is not None:
