@@ -197,13 +197,16 @@ template <int DT, int C>
 __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp_max_kernel(
     const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
     const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
-    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat) {
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb) {
     typedef PnCfg<DT> Cfg;
     constexpr int NP = Cfg::NP;
     constexpr int STAGE_BYTES = Cfg::CPS * Cfg::UPC * 1024;
     constexpr int N_STAGES = kCt / Cfg::CPS;
     constexpr int A2_BYTES = Cfg::A2_UNITS * 1024;
-    constexpr int PTS_PER_CHUNK = kPnWaves * NP * 32;
+    // Small clouds share a workgroup: cpb (1, 2 or 4) clouds per block, kPnWaves / cpb waves each, all fed by the
+    // same stream of conv3 weights.
+    const int wpc = kPnWaves / cpb;                       // waves per cloud
+    const int PTS_PER_CHUNK = wpc * NP * 32;              // points of one cloud per chunk
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w3s = smem;                                                         // [2][STAGE_BYTES]
@@ -211,14 +214,18 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
     float* a1s = reinterpret_cast<float*>(a2s + A2_BYTES);                    // [64][4]
     float* c1s = a1s + kC1 * 4;                                               // [64]
     float* c2s = c1s + kC1;                                                   // [128]
-    int* bmax = reinterpret_cast<int*>(c2s + kC2);                            // [1024] running max (int keys)
+    int* bmax = reinterpret_cast<int*>(c2s + kC2);                            // [cpb][1024] running max (int keys)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
     const int r = lane & 31;
     const int h = lane >> 5;
-    const int b = blockIdx.x;
+    const int cl = wave / wpc;                            // this wave's cloud within the block
+    const int lw = wave - cl * wpc;
+    int b = blockIdx.x * cpb + cl;
+    if (b >= B) b = B - 1;                                // a surplus slot recomputes the last cloud; its result is not stored
+    int* wmax = bmax + cl * kC3;
 
     // ---- resident tables
     for (int i = tid; i < kC1 * 4; i += kPnThreads) {
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
     }
     for (int i = tid; i < kC1; i += kPnThreads) c1s[i] = c1[i];
     for (int i = tid; i < kC2; i += kPnThreads) c2s[i] = c2[i];
-    for (int i = tid; i < kC3; i += kPnThreads) bmax[i] = (int)0x80000000;
+    for (int i = tid; i < cpb * kC3; i += kPnThreads) bmax[i] = (int)0x80000000;
     // conv2 weights A2 [128][64] -> A-operand fragment order.  Channel order along k is
     // ch1(h, t) = 32h + t, the order conv1 leaves its outputs in.
     for (int i = tid; i < Cfg::A2_UNITS * 64; i += kPnThreads) {
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
         bf16x8 Xb[(DT == DVQ_BF16) ? NP : 1][8];
         float Xf[(DT == DVQ_F32) ? NP : 1][64];
         {
-            const int nbase = chunk * PTS_PER_CHUNK + wave * NP * 32 + r;
+            const int nbase = chunk * PTS_PER_CHUNK + lw * NP * 32 + r;
             // one call per point tile, spelled out so that every fragment index is a constant
 #define DVQ_PN_TILE(np)                                                                                           \
     if constexpr (NP > np) {                                                                                      \
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
 #pragma unroll
                     for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[np][i]);
                 m = fmaxf(m, __shfl_xor(m, 32, 64));
-                if (h == 0) atomicMax(&bmax[(st * Cfg::CPS + cc) * 32 + r], f32_key(m));
+                if (h == 0) atomicMax(&wmax[(st * Cfg::CPS + cc) * 32 + r], f32_key(m));
             }
             __syncthreads();  // next stage landed; this buffer is free for the stage after
         }
@@ -329,25 +336,32 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
 
     // ---- epilogue: bias (and ReLU for the STN trunk) after the max -- both are monotone,
     // so max_n act(h_n + c) == act(max_n h_n + c) exactly.
-    for (int ch = tid; ch < kC3; ch += kPnThreads) {
-        float v = key_f32(bmax[ch]) + c3[ch];
+    for (int i = tid; i < cpb * kC3; i += kPnThreads) {
+        const int cloud = blockIdx.x * cpb + i / kC3, ch = i % kC3;
+        if (cloud >= B) break;
+        float v = key_f32(bmax[i]) + c3[ch];
         if (relu3) v = v > 0.f ? v : 0.f;
-        feat[(int64_t)b * kC3 + ch] = v;
+        feat[(int64_t)cloud * kC3 + ch] = v;
     }
 }
 
 template <int DT>
-static size_t pn_lds_bytes() {
+static size_t pn_lds_bytes(int cpb) {
     typedef PnCfg<DT> Cfg;
-    return 2 * (size_t)Cfg::CPS * Cfg::UPC * 1024 + (size_t)Cfg::A2_UNITS * 1024 + (kC1 * 4 + kC1 + kC2) * 4 + kC3 * 4;
+    return 2 * (size_t)Cfg::CPS * Cfg::UPC * 1024 + (size_t)Cfg::A2_UNITS * 1024 + (kC1 * 4 + kC1 + kC2) * 4 + (size_t)cpb * kC3 * 4;
 }
 
 template <int DT, int C>
 static int pn_launch(const float* x, const float* trans, int B, int N, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
     auto kern = pointnet_mlp_max_kernel<DT, C>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pn_lds_bytes<DT>(), "pointnet_mlp_max")) return rc;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(kPnThreads), pn_lds_bytes<DT>(), st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
-                       reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat);
+    // clouds per workgroup: as many as fit a chunk of 8 waves x NP x 32 points, at most 4 (LDS for the running maxima)
+    const int pts_per_wave = PnCfg<DT>::NP * 32;
+    int cpb = 1;
+    while (cpb < 4 && N <= (kPnWaves / (2 * cpb)) * pts_per_wave) cpb *= 2;
+    const size_t lds = pn_lds_bytes<DT>(cpb);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "pointnet_mlp_max")) return rc;
+    hipLaunchKernelGGL(kern, dim3((B + cpb - 1) / cpb), dim3(kPnThreads), lds, st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
+                       reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat, B, cpb);
     return check_launch("pointnet_mlp_max");
 }
 

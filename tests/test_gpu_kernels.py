@@ -127,11 +127,14 @@ def test_pointnet_bf16_tolerance():
     assert e_t <= 2e-2 and e_f <= 3e-2
 
 
-@pytest.mark.parametrize("N", [1, 31, 257, 1024, 1025, 3000])
-def test_pointnet_ragged_point_counts(N):
+@pytest.mark.parametrize("N,B", [(1, 3), (31, 3), (83, 5), (123, 7), (128, 4), (129, 6), (212, 5), (256, 2), (257, 3),
+                                 (1024, 3), (1025, 3), (3000, 3)])
+def test_pointnet_ragged_point_counts(N, B):
+    """Point counts around every chunk and tile boundary.  Clouds of up to 256 points share a workgroup (two or
+    four clouds per block), so the batch sizes include ones that leave a block partly empty."""
     sd = synth.gennet_state_dict(0, with_prior=False)
     enc = _encoder("obj_encoder_pos.", 4)
-    x = synth.object_clouds(3, 3000, seed=3)[:, :, :N].contiguous()
+    x = synth.object_clouds(B, 3000, seed=3)[:, :, :N].contiguous()
     ref_f, ref_t = O.pointnet_encoder(x, sd, "obj_encoder_pos.")
     feat, trans, _ = enc(x.to(DEV))
     assert rel_err(trans, ref_t) <= 1e-5 and rel_err(feat, ref_f) <= 1e-5
