@@ -28,7 +28,6 @@
 namespace dvq {
 
 constexpr int kPgWaves = 4;
-constexpr int kPgStageKB = 1;   // k-blocks (of 32 features) per LDS stage
 constexpr int kPgRing = 3;      // stage buffers
 constexpr int kPgMaxTaps = 10;
 
@@ -82,15 +81,15 @@ enum { PG_PACK = 0, PG_GATE = 1, PG_ROWS = 2 };
 // stages ago, which is immediately refilled.
 // A 128 x 128 output tile per workgroup is all a [4096 x 1024] product leaves for each of the 256
 // CUs, so every CU pulls 16 KiB through L2 per k-block of 32 features: the product is bound by
-// L2 -> LDS bandwidth (64 FLOP per byte), not by the matrix cores.  KS = 1 and R = 3 (48 KiB) keep
-// two loads in flight per wave, which is enough to saturate that path, and leave room in LDS for
-// workgroups of the point-cloud encoder that runs beside the prior on another stream.
-template <int EPI, int NO>
+// L2 -> LDS bandwidth (64 FLOP per byte), not by the matrix cores.  With 4096 or more rows KS = 1
+// and R = 3 (48 KiB) keep two loads in flight per wave, which is enough to saturate that path, and
+// leave room in LDS for workgroups of the point-cloud encoder that runs beside the prior on another
+// stream; smaller batches are latency-bound and take KS = 2 (half as many barriers per product).
+template <int EPI, int NO, int KS>
 __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PgJobDev& job = jobs.j[blockIdx.z];
     constexpr int NS = 1;
-    constexpr int KS = kPgStageKB;                              // k-blocks per stage
     constexpr int W_UNITS = NO * KS * 2;
     constexpr int X_UNITS = kPgWaves * KS * 2;
     constexpr int STAGE_BYTES = (W_UNITS + X_UNITS) * 1024;
@@ -297,6 +296,94 @@ __global__ void prior_embed_kernel(const int64_t* __restrict__ idx, int64_t idx_
     out[t] = pack8(v);
 }
 
+
+// One grid cell of the sampling loop in a single launch (DVQ-VAE/network/pixelcnn/models.py:189-196): softmax of the
+// logits row, renormalisation, inverse-CDF draw with the row's uniform u in [0,1), the index written into the grid and
+// its embedding row written as the packed input of the next cell.  One wave per row; lane l owns classes
+// [l*per, (l+1)*per) so the running sum is a lane-local prefix plus one wave scan.  Probabilities are formed in fp32 as
+// the softmax does, the cumulative sum in fp64; index = number of cdf entries <= u, clamped to the last class.
+constexpr int kPsMaxPer = 16;   // classes per lane: up to 1024 classes
+
+__global__ __launch_bounds__(256) void prior_sample_kernel(const float* __restrict__ logits, int n, int M,
+                                                           const double* __restrict__ u, int64_t u_stride,
+                                                           int64_t* __restrict__ x_out, int64_t x_stride,
+                                                           const float* __restrict__ table, int d, uint4* __restrict__ emb_out) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int per = (n + 63) / 64;
+    const float* row = logits + (int64_t)m * n;
+    float v[kPsMaxPer];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < kPsMaxPer; ++i) {
+        const int k = lane * per + i;
+        v[i] = (i < per && k < n) ? row[k] : -__builtin_inff();
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPsMaxPer; ++i) {
+        v[i] = (i < per) ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    float sum2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPsMaxPer; ++i) {
+        v[i] = v[i] / sum;
+        sum2 += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum2 += __shfl_xor(sum2, o, 64);
+    double local = 0.0;
+    double c[kPsMaxPer];
+#pragma unroll
+    for (int i = 0; i < kPsMaxPer; ++i) {
+        local += (double)(v[i] / sum2);
+        c[i] = local;
+    }
+    // inclusive wave scan of the lane totals
+    double incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const double before = incl - local;
+    const double total = __shfl(incl, 63, 64);
+    const double uu = u[(int64_t)m * u_stride];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < kPsMaxPer; ++i) {
+        const int k = lane * per + i;
+        if (i < per && k < n && (before + c[i]) / total <= uu) ++cnt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    const int idx = cnt < n - 1 ? cnt : n - 1;
+    if (lane == 0) x_out[(int64_t)m * x_stride] = (int64_t)idx;
+    if (emb_out) {   // packed[fb][sb][s][lane (c,h)] <- table[idx][32fb + 16s + 8(j>>2) + 4h + (j&3)]
+        const int SB = (M + 31) / 32;
+        const int sbk = m >> 5, cc = m & 31;
+        const float* src_row = table + (int64_t)idx * d;
+        for (int piece = lane; piece < (d / 32) * 4; piece += 64) {
+            const int fb = piece >> 2, s2 = (piece >> 1) & 1, hh = piece & 1;
+            const float* src = src_row + 32 * fb + 16 * s2 + 4 * hh;
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = src[8 * (j >> 2) + (j & 3)];
+            const uint4 pk = pack8(e);
+            // the last row also fills the unused rows of its 32-row block, as prior_embed does
+            const int reps = (m == M - 1) ? (SB * 32 - m) : 1;
+            for (int rr = 0; rr < reps; ++rr) emb_out[((int64_t)(fb * SB + sbk) * 2 + s2) * 64 + hh * 32 + cc + rr] = pk;
+        }
+    }
+}
+
 }  // namespace dvq
 
 using namespace dvq;
@@ -320,6 +407,16 @@ extern "C" int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const flo
     hipLaunchKernelGGL(prior_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), idx, idx_stride, table, V, M, d,
                        reinterpret_cast<uint4*>(out));
     return check_launch("prior_embed");
+}
+
+extern "C" int dvq_prior_sample(const float* logits, int n_classes, int M, const double* u, int64_t u_stride, int64_t* x_out,
+                                int64_t x_stride, const float* table, int d, void* emb_out, void* stream) {
+    if (!logits || !u || !x_out || M < 1) return fail(DVQ_EINVAL, "prior_sample: bad arguments");
+    if (n_classes < 1 || n_classes > 64 * kPsMaxPer) return fail(DVQ_EINVAL, "prior_sample: 1..%d classes (got %d)", 64 * kPsMaxPer, n_classes);
+    if (emb_out && (!table || d < 32 || (d % 32))) return fail(DVQ_EINVAL, "prior_sample: embedding width must be a multiple of 32");
+    hipLaunchKernelGGL(prior_sample_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logits, n_classes, M, u, u_stride, x_out,
+                       x_stride, table, d, reinterpret_cast<uint4*>(emb_out));
+    return check_launch("prior_sample");
 }
 
 extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, void* stream) {
@@ -349,28 +446,34 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
         if (epilogue == PG_ROWS && !s.out_rows) return fail(DVQ_EINVAL, "prior_gemm: out_rows missing");
     }
     const int SB = (M + 31) / 32;
+    const int ks = M >= 4096 ? 1 : 2;   // k-blocks of 32 features per LDS stage
     for (int j = 0; j < n_jobs; ++j)
         for (int t = 0; t < jobs[j].n_taps; ++t)
-            if (jobs[j].taps[t].k_blocks % kPgStageKB) return fail(DVQ_EINVAL, "prior_gemm: k_blocks must be a multiple of %d", kPgStageKB);
+            if (jobs[j].taps[t].k_blocks % 2) return fail(DVQ_EINVAL, "prior_gemm: k_blocks must be even");
     // 128 output features per workgroup unless that leaves CUs without one; then 64
     const int gy = (SB + kPgWaves - 1) / kPgWaves;
     const int no = ((N / 128) * gy * n_jobs >= kNumCU || (N % 64) != 0 || (epilogue == PG_GATE && (N % 128) != 0)) ? 4 : 2;
     const dim3 grid(N / (32 * no), gy, n_jobs);
-    const size_t lds = (size_t)kPgRing * (no * kPgStageKB * 2 + kPgWaves * kPgStageKB * 2) * 1024;
+    const size_t lds = (size_t)kPgRing * (no * ks * 2 + kPgWaves * ks * 2) * 1024;
     hipStream_t st = as_stream(stream);
     const dim3 blk(kPgWaves * 64);
-#define DVQ_PG_LAUNCH(E)                                                                                            \
-    do {                                                                                                            \
-        const void* fn = no == 4 ? reinterpret_cast<const void*>(prior_gemm_kernel<E, 4>)                          \
-                                 : reinterpret_cast<const void*>(prior_gemm_kernel<E, 2>);                         \
-        if (int rc = ensure_dynamic_lds(fn, lds, "prior_gemm")) return rc;                                          \
-        if (no == 4) hipLaunchKernelGGL((prior_gemm_kernel<E, 4>), grid, blk, lds, st, dev, M, N, relu);           \
-        else hipLaunchKernelGGL((prior_gemm_kernel<E, 2>), grid, blk, lds, st, dev, M, N, relu);                   \
+#define DVQ_PG_LAUNCH2(E, NO_, KS_)                                                                      \
+    do {                                                                                                 \
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_gemm_kernel<E, NO_, KS_>), lds, "prior_gemm")) return rc; \
+        hipLaunchKernelGGL((prior_gemm_kernel<E, NO_, KS_>), grid, blk, lds, st, dev, M, N, relu);       \
+    } while (0)
+#define DVQ_PG_LAUNCH(E)                                  \
+    do {                                                  \
+        if (no == 4 && ks == 1) DVQ_PG_LAUNCH2(E, 4, 1);  \
+        else if (no == 4) DVQ_PG_LAUNCH2(E, 4, 2);        \
+        else if (ks == 1) DVQ_PG_LAUNCH2(E, 2, 1);        \
+        else DVQ_PG_LAUNCH2(E, 2, 2);                     \
     } while (0)
     if (epilogue == PG_PACK) DVQ_PG_LAUNCH(PG_PACK);
     else if (epilogue == PG_GATE) DVQ_PG_LAUNCH(PG_GATE);
     else if (epilogue == PG_ROWS) DVQ_PG_LAUNCH(PG_ROWS);
     else return fail(DVQ_EINVAL, "prior_gemm: unknown epilogue %d", epilogue);
+#undef DVQ_PG_LAUNCH2
 #undef DVQ_PG_LAUNCH
     return check_launch("prior_gemm");
 }

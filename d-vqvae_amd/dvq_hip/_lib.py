@@ -61,6 +61,7 @@ SIGNATURES = {
     "dvq_prior_pack_weight": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_gemm": (c_int, [POINTER(DvqPriorJob), c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dvq_prior_sample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
     "dvq_mano_lbs_backward": (c_int, [c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,

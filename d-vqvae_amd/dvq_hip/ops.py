@@ -320,3 +320,19 @@ def prior_gemm(jobs, M: int, N: int, epilogue: int, relu: bool, ref: torch.Tenso
     with torch.cuda.device(ref.device), _timed("prior_gemm", (M, N, len(jobs)), ref):
         rc = _lib.load().dvq_prior_gemm(arr, len(jobs), M, N, epilogue, int(relu), _stream(ref))
     _lib.check(rc, "dvq_prior_gemm")
+
+
+def prior_sample(logits: torch.Tensor, u: torch.Tensor, x_out: torch.Tensor, table: Optional[torch.Tensor] = None,
+                 emb_out: Optional[torch.Tensor] = None) -> None:
+    """x_out[m] <- inverse-CDF draw from softmax(logits[m]) at uniform u[m]; u and x_out may be strided columns of
+    [M, cells] tensors.  With `table`/`emb_out` the chosen embedding rows are written in packed form."""
+    _need_gpu(logits)
+    if logits.dtype != torch.float32 or u.dtype != torch.float64 or x_out.dtype != torch.int64:
+        raise RuntimeError("prior_sample: logits float32, u float64, x_out int64 expected")
+    M, n = logits.shape
+    if u.dim() != 1 or x_out.dim() != 1 or u.shape[0] != M or x_out.shape[0] != M:
+        raise RuntimeError("prior_sample: u and x_out must be 1-d views with one entry per row")
+    with torch.cuda.device(logits.device):
+        rc = _lib.load().dvq_prior_sample(_p(logits), n, M, _p(u), u.stride(0), _p(x_out), x_out.stride(0), _p(table),
+                                          0 if table is None else table.shape[1], _p(emb_out), _stream(logits))
+    _lib.check(rc, "dvq_prior_sample")

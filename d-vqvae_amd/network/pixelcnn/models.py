@@ -267,6 +267,10 @@ class GatedPixelCNN(nn.Module):
                 ops.prior_gemm([ops.prior_job([(XH[L], wo1, kb)], bo1, out_packed=HID)], B, bo1.numel(), ops.PRIOR_PACK, True, emb)
                 ops.prior_gemm([ops.prior_job([(HID, wo2, bo1.numel() // 32)], bo2, out_rows=logits)], B, n_out, ops.PRIOR_ROWS,
                                False, emb)
+                if uniforms is not None and not return_probs:
+                    # softmax, draw, grid write and embedding of the drawn code in one launch
+                    ops.prior_sample(logits, uniforms[:, i * W + j], x[:, i, j], emb, XV[0][i][j])
+                    continue
                 probs = F.softmax(logits, -1)
                 probs = probs / probs.sum(dim=1, keepdim=True)
                 if return_probs:

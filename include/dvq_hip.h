@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 101   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 102   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -227,6 +227,12 @@ int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K
 /* out(packed)[m] = table[idx[m*idx_stride]]: embedding rows of sampled indices, d features */
 int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, void* out, void* stream);
 int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, void* stream);
+/* One cell of the sampling loop (models.py:189-196): p = softmax(logits[m, :]) / sum, x = inverse CDF of p at the
+ * uniform u[m*u_stride] in [0,1) (fp64 running sum; the number of cdf entries <= u, clamped to n_classes-1), written to
+ * x_out[m*x_stride]; if emb_out is given, row x of `table` [n_classes, d] is also written there as packed activations
+ * (the next cell's input).  logits: fp32 [M, n_classes], n_classes <= 1024. */
+int dvq_prior_sample(const float* logits, int n_classes, int M, const double* u, int64_t u_stride, int64_t* x_out,
+                     int64_t x_stride, const float* table, int d, void* emb_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,31 @@ def test_prior_bf16_kernels_vs_fp32():
     assert torch.equal(x16c[0], x16[40])       # and of batch size, down to one
 
 
+def test_prior_sample_kernel_equals_softmax_cumsum_searchsorted():
+    """The fused cell sampler against the torch formulation it replaces (softmax, renormalise, fp64 cumulative
+    sum, searchsorted) and against prior_embed for the packed embedding rows."""
+    from dvq_hip import ops, rng
+    from dvq_hip.rng import sample_rows
+    g = torch.Generator(DEV).manual_seed(4)
+    for M, n in ((100, 512), (4096, 512), (33, 128), (7, 1000)):
+        logits = torch.randn(M, n, device=DEV, generator=g) * 3
+        logits[:, n // 2:] -= 1e4 * (torch.rand(M, 1, device=DEV, generator=g) < 0.3)      # masked-out classes
+        u = rng.uniforms(torch.arange(M, device=DEV), 9, seed=3)
+        u[0, 4], u[1 % M, 4] = 0.0, 1.0 - 2.0 ** -53                                         # the ends of [0,1)
+        x = torch.zeros(M, 3, 3, dtype=torch.int64, device=DEV)
+        d = 64
+        table = torch.randn(n, d, device=DEV, generator=g)
+        emb = ops.prior_packed_empty(M, d, DEV, True)
+        ops.prior_sample(logits, u[:, 4], x[:, 1, 1], table, emb)
+        probs = torch.softmax(logits, -1)
+        ref = sample_rows(probs / probs.sum(1, keepdim=True), u[:, 4].contiguous())
+        assert int((x[:, 1, 1] != ref).sum()) <= max(1, M // 2000), int((x[:, 1, 1] != ref).sum())
+        assert int(x[:, 1, 1].max()) < n and int(x.sum()) == int(x[:, 1, 1].sum())           # only that cell was written
+        emb_ref = ops.prior_packed_empty(M, d, DEV, True)
+        ops.prior_embed(x[:, 1, 1], table, emb_ref)
+        assert torch.equal(emb, emb_ref)
+
+
 def test_gen_bf16_stated_tolerance():
     """bf16 encoders: vertices within 2 mm of the fp32 path on a ~0.2 m hand (stated
     tolerance), object-code agreement reported."""
