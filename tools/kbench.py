@@ -98,6 +98,23 @@ def prior():
             print(f"prior.generate B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  ({1.22e9 * B / ms / 1e9:7.1f} TFLOP/s useful)", flush=True)
 
 
+def dvqvae():
+    """The encode path (DVQVAE.forward, eval): two object encoders, six hand-part encoders + MLPs, seven codebook searches."""
+    from network.DVQVAE import DVQVAE
+    model = DVQVAE()
+    model.load_state_dict(synth.dvqvae_state_dict(0))
+    model = model.to(dev).eval()
+    for B in (4096, 64):
+        obj = synth.object_clouds_device(B, 3000, 7, dev)
+        hand = torch.randn(B, 3, 778, device=dev) * 0.05
+        for dt in (torch.bfloat16, torch.float32):
+            import dvq_hip
+            dvq_hip.set_compute_dtype(model, dt)
+            with torch.no_grad():
+                ms = timeit(lambda: model(obj, hand), iters=3, warm=1)
+            print(f"DVQVAE.forward(eval) B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  {B / ms * 1e3:10.0f} hands/s", flush=True)
+
+
 def tta():
     import mano as M
     from dvq_hip.mano_io import Struct
