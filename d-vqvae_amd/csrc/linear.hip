@@ -18,6 +18,10 @@ namespace dvq {
 
 constexpr int kLinWaves = 4;
 
+// RM x RN tiles of 32x32 per wave: every x fragment loaded feeds RN MFMA chains and every W fragment RM, so the
+// L1/L2 traffic per FLOP falls by 2 RM RN / (RM + RN).  Each output element is the same k-ordered fmaf chain
+// whatever the tiling, so the result does not depend on RM, RN.
+template <int RM, int RN>
 __global__ __launch_bounds__(kLinWaves * 64) void linear_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, const float* __restrict__ bias, int M, int K,
     int N, int relu, int add_id3, float* __restrict__ y, int64_t ldy) {
@@ -25,46 +29,77 @@ __global__ __launch_bounds__(kLinWaves * 64) void linear_kernel(
     const int wave = threadIdx.x >> 6;
     const int r = lane & 31;
     const int h = lane >> 5;
-    const int n_tiles_n = (N + 31) / 32;
+    const int n_tiles_n = (N + 32 * RN - 1) / (32 * RN);
     const int tile = blockIdx.x * kLinWaves + wave;
     const int tm = tile / n_tiles_n;
     const int tn = tile % n_tiles_n;
-    if (tm * 32 >= M) return;
-    int rowx = tm * 32 + r; if (rowx >= M) rowx = M - 1;
-    int roww = tn * 32 + r; if (roww >= N) roww = N - 1;
-    const float* xp = x + (int64_t)rowx * ldx;
-    const float* wp = W + (int64_t)roww * K;
-
-    f32x16 acc;
+    if (tm * 32 * RM >= M) return;
+    const float* xp[RM];
+    const float* wp[RN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < RM; ++i) {
+        int row = (tm * RM + i) * 32 + r;
+        if (row >= M) row = M - 1;
+        xp[i] = x + (int64_t)row * ldx;
+    }
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        int row = (tn * RN + j) * 32 + r;
+        if (row >= N) row = N - 1;
+        wp[j] = W + (int64_t)row * K;
+    }
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     int k0 = 0;
     const int k_vec_end = (K / 8) * 8;
-#pragma unroll 4
+#pragma unroll 2
     for (; k0 < k_vec_end; k0 += 8) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k0 + 4 * h);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(wp + k0 + 4 * h);
+        f32x4 a[RM], b[RN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+        for (int i = 0; i < RM; ++i) a[i] = *reinterpret_cast<const f32x4*>(xp[i] + k0 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) b[j] = *reinterpret_cast<const f32x4*>(wp[j] + k0 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
     }
     for (; k0 < K; k0 += 2) {  // tail: natural order, zero beyond K
         const int k = k0 + h;
-        const float a = k < K ? xp[k] : 0.f;
-        const float b = k < K ? wp[k] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    const int col = tn * 32 + r;
-    if (col >= N) return;
-    const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (row < M) {
-            float v = acc[i] + bv;
-            if (relu) v = v > 0.f ? v : 0.f;
-            if (add_id3 && (col % 4) == 0) v += 1.f;
-            y[(int64_t)row * ldy + col] = v;
-        }
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const float a = k < K ? xp[i][k] : 0.f;
+                const float b = k < K ? wp[j][k] : 0.f;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int col = (tn * RN + j) * 32 + r;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (tm * RM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < M) {
+                    float v = acc[i][j][e] + bv;
+                    if (relu) v = v > 0.f ? v : 0.f;
+                    if (add_id3 && (col % 4) == 0) v += 1.f;
+                    y[(int64_t)row * ldy + col] = v;
+                }
+            }
     }
 }
 
@@ -146,9 +181,16 @@ extern "C" int dvq_linear(const float* x, int64_t ldx, const float* W, const flo
         else
             hipLaunchKernelGGL((linear_skinny_kernel<kSkinnyM>), dim3(grid), dim3(256), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy);
     } else {
-        const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
-        const int blocks = (tiles + kLinWaves - 1) / kLinWaves;
-        hipLaunchKernelGGL(linear_kernel, dim3(blocks), dim3(kLinWaves * 64), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy);
+        // the largest per-wave tile that still leaves every SIMD a wave (4 x 256 CUs)
+        auto waves = [&](int rm, int rn) { return (int64_t)((M + 32 * rm - 1) / (32 * rm)) * ((N + 32 * rn - 1) / (32 * rn)); };
+        const int64_t enough = 4 * kNumCU;
+#define DVQ_LIN_LAUNCH(RM, RN)                                                                                       \
+    hipLaunchKernelGGL((linear_kernel<RM, RN>), dim3((unsigned)((waves(RM, RN) + kLinWaves - 1) / kLinWaves)),      \
+                       dim3(kLinWaves * 64), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy)
+        if (waves(2, 2) >= enough) DVQ_LIN_LAUNCH(2, 2);
+        else if (waves(2, 1) >= enough) DVQ_LIN_LAUNCH(2, 1);
+        else DVQ_LIN_LAUNCH(1, 1);
+#undef DVQ_LIN_LAUNCH
     }
     return check_launch("linear");
 }
