@@ -87,6 +87,9 @@ enum { PG_PACK = 0, PG_GATE = 1, PG_ROWS = 2 };
 // stream; smaller batches are latency-bound and take KS = 2 (half as many barriers per product).
 template <int EPI, int NO, int KS>
 __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
+    // These products form a long dependent chain of short launches; when another stream's long-running kernel
+    // (the point-cloud encoder) shares the CU, win the SIMD's issue arbitration so the chain keeps its pace.
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PgJobDev& job = jobs.j[blockIdx.z];
     constexpr int NS = 1;
