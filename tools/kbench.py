@@ -115,6 +115,17 @@ def dvqvae():
             print(f"DVQVAE.forward(eval) B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  {B / ms * 1e3:10.0f} hands/s", flush=True)
 
 
+def gen():
+    """End-to-end generation (gen + call-site MANO) at small batch sizes: the reference calls it with one object at a time."""
+    from dvq_hip.pipeline import GraspGenerator
+    for dt in (torch.bfloat16, torch.float32):
+        g = GraspGenerator.synthetic(dev, seed=0, dtype=dt)
+        for B in (1, 16, 256):
+            obj = synth.object_clouds_device(B, 3000, 11, dev)
+            ms = timeit(lambda: g.generate(obj), iters=5, warm=2)
+            print(f"generate B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  {B / ms * 1e3:10.0f} grasps/s", flush=True)
+
+
 def tta():
     import mano as M
     from dvq_hip.mano_io import Struct
