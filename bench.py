@@ -31,11 +31,13 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X
 FLOP_PER_POINT = {3: 2 * (3 * 64 + 64 * 128 + 128 * 1024), 4: 2 * (4 * 64 + 64 * 128 + 128 * 1024)}
 
 
-def timed_steps(fn, steps, warmup, device, barrier):
+def timed_steps(fn, steps, warmup, device, barrier, kernel_timers=False):
     for _ in range(warmup):
         fn()
     barrier()
     torch.cuda.synchronize(device)
+    if kernel_timers:
+        ops.enable_timers(True)      # per-launch HIP events over the timed region only
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
@@ -49,8 +51,9 @@ def kernel_stats(name_prefix):
     best = None
     for name, recs in (ops.TIMERS or {}).items():
         if name.startswith(name_prefix):
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            cand = (sum(ms) / len(ms), len(ms), recs[0][2], name)
+            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            alone = [a.elapsed_time(b) for a, b, _, main in recs if main]
+            cand = (sum(ms) / len(ms), len(ms), recs[0][2], name, (sum(alone) / len(alone)) if alone else None)
             if best is None or cand[0] * cand[1] > best[0] * best[1]:
                 best = cand
     return best
@@ -197,8 +200,7 @@ def main():
             verts = parallel.gather_rows(verts, world * B)
         return verts
 
-    ops.enable_timers(True)
-    elapsed = timed_steps(step, args.steps, args.warmup, device, barrier)
+    elapsed = timed_steps(step, args.steps, args.warmup, device, barrier, kernel_timers=True)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,7 +225,7 @@ def main():
                        "parallelism": f"dp{world}"},
         }
         if ks is not None:
-            avg_ms, launches, (kb, kc, kn), name = ks
+            avg_ms, launches, (kb, kc, kn), name, alone_ms = ks
             flops = float(kb) * kn * FLOP_PER_POINT[kc]
             ach = flops / avg_ms / 1e9
             # HBM bytes per launch from the FETCH_SIZE (x2, the gfx950 correction for 16-B-per-lane streams) and
@@ -236,6 +238,10 @@ def main():
                                   "traffic_note": "HBM bytes per launch, PMC passes in profiles/r1c_pmc_fetch_write.txt; "
                                                   "algorithmic bytes 2.134e8",
                                   "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
+                                  # half of the launches share the GPU with the prior running on the other stream; the
+                                  # launches that had it to themselves (first object encoder) for comparison
+                                  "avg_launch_ms_uncontended": None if alone_ms is None else round(alone_ms, 4),
+                                  "frac_uncontended": None if alone_ms is None else round(flops / alone_ms / 1e9 / PEAK_TFLOPS[args.dtype], 4),
                                   "flop_per_launch": flops}
 
     if not args.no_extras and world == 1:

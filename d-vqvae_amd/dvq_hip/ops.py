@@ -16,7 +16,7 @@ from ._lib import DVQ_BF16, DVQ_F32, DvqHandMesh, DvqManoConsts, DvqPointMlp, Dv
 
 
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
-# roofline figure): TIMERS[name] collects (start_event, end_event, work) per launch.
+# roofline figure): TIMERS[name] collects (start_event, end_event, work, on_default_stream) per launch.
 TIMERS = None
 
 
@@ -38,7 +38,9 @@ class _timed:
     def __exit__(self, *exc):
         if TIMERS is not None:
             self.e1.record(torch.cuda.current_stream(self.ref.device))
-            TIMERS.setdefault(self.name, []).append((self.e0, self.e1, self.work))
+            dev = self.ref.device
+            TIMERS.setdefault(self.name, []).append((self.e0, self.e1, self.work,
+                                                     torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev)))
 
 
 def _p(t: Optional[torch.Tensor]):
