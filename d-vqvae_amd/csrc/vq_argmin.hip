@@ -400,7 +400,20 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_kernel(
 // One wave owns 32 latents; z fragments are re-read (L1/L2) for every code tile and the
 // codebook tile is staged through LDS in chunks of CH dims.  Slower; used for the shapes
 // the register path does not cover (e.g. the 1024-wide object codebook).
-template <int DT, int WAVES>
+// SPLIT: the code tiles are spread over gridDim.y workgroups (few latents, long rows: more waves than n/32);
+// every workgroup folds its winner into idx_out with a 64-bit atomic min on (order-preserving distance bits,
+// code), and vq_unpack_key_kernel strips the distance afterwards.  idx_out must have been filled with 0xFF bytes.
+__device__ __forceinline__ unsigned long long vq_pack_key(float d, int code) {
+    const unsigned b = __builtin_bit_cast(unsigned, d);
+    const unsigned ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)ord << 32) | (unsigned)code;
+}
+__global__ void vq_unpack_key_kernel(int64_t* __restrict__ idx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = idx[i] & 0xFFFFFFFFll;
+}
+
+template <int DT, int WAVES, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void vq_argmin_generic_kernel(
     const typename VqTraits<DT>::elem* __restrict__ z, const char* __restrict__ packed,
     const float* __restrict__ e2, int64_t n, int D, int n_tiles, int64_t* __restrict__ idx_out) {
@@ -427,7 +440,8 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_generic_kernel(
         }
         const float z2 = part + __shfl_xor(part, 32, 64);
         Best best; best.d = __builtin_inff(); best.k = 0;
-        for (int t = 0; t < n_tiles; ++t) {
+        const int t_begin = SPLIT ? (int)blockIdx.y : 0, t_step = SPLIT ? (int)gridDim.y : 1;
+        for (int t = t_begin; t < n_tiles; t += t_step) {
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -436,18 +450,38 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_generic_kernel(
                 __syncthreads();
                 stage_copy(packed + ((int64_t)t * U + u0) * 1024, e_lds, nu * 1024, tid, WAVES * 64);
                 __syncthreads();
-                for (int s = 0; s < nu; ++s) {
+                // four z fragment loads (global, L2-resident) are issued before the first of their MFMAs, so the
+                // loop pays one load latency per four steps
+                for (int s0 = 0; s0 < nu; s0 += 4) {
                     if constexpr (DT == DVQ_BF16) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(e_lds + s * 1024 + lane * 16);
-                        const u16x8 raw = *reinterpret_cast<const u16x8*>(
-                            reinterpret_cast<const unsigned short*>(zr) + vq_dim_bf16(u0 + s, h, 0));
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, raw), acc, 0, 0, 0);
-                    } else {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(e_lds + s * 1024 + lane * 16);
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(
-                            reinterpret_cast<const float*>(zr) + vq_dim_f32(u0 + s, h, 0, D));
+                        u16x8 raw[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+                        for (int j = 0; j < 4; ++j) {
+                            const int sj = (s0 + j < nu) ? s0 + j : nu - 1;
+                            raw[j] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const unsigned short*>(zr) + vq_dim_bf16(u0 + sj, h, 0));
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (s0 + j < nu) {
+                                const bf16x8 a = *reinterpret_cast<const bf16x8*>(e_lds + (s0 + j) * 1024 + lane * 16);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, raw[j]), acc, 0, 0, 0);
+                            }
+                        }
+                    } else {
+                        f32x4 bq[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int sj = (s0 + j < nu) ? s0 + j : nu - 1;
+                            bq[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(zr) + vq_dim_f32(u0 + sj, h, 0, D));
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (s0 + j < nu) {
+                                const f32x4 a = *reinterpret_cast<const f32x4*>(e_lds + (s0 + j) * 1024 + lane * 16);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j][i], acc, 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -465,7 +499,11 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_generic_kernel(
             }
         }
         merge_halves(best);
-        if (h == 0 && live) idx_out[grp * (WAVES * 32) + wave * 32 + r] = (int64_t)best.k;
+        if (h == 0 && live) {
+            int64_t* dst = idx_out + grp * (WAVES * 32) + wave * 32 + r;
+            if (SPLIT) atomicMin(reinterpret_cast<unsigned long long*>(dst), vq_pack_key(best.d, best.k));
+            else *dst = (int64_t)best.k;
+        }
     }
 }
 
@@ -560,6 +598,26 @@ static int launch_search(const void* z, const char* ws, const VqPlan& p, int64_t
         if (D == 256) return launch_reg<DVQ_F32, 256, 1, 8>(z, ws, p, n, idx_out, st);
         if (D == 128) return launch_reg<DVQ_F32, 128, 2, 8>(z, ws, p, n, idx_out, st);
         if (D == 64) return launch_reg<DVQ_F32, 64, 2, 8>(z, ws, p, n, idx_out, st);
+    }
+    // few latents (the object codebook is searched with one 1024-d row per object): one wave per workgroup, so that the
+    // n/32 waves spread over as many CUs as possible instead of sharing a quarter of them
+    if (n <= (int64_t)32 * 4 * kNumCU) {
+        const int64_t groups = (n + 31) / 32;
+        int split = (int)((4 * kNumCU + groups - 1) / groups);     // aim at four waves per CU
+        if (split > p.n_tiles) split = p.n_tiles;
+        if (split > 1) {
+            if (hipMemsetAsync(idx_out, 0xFF, (size_t)n * sizeof(int64_t), st) != hipSuccess)
+                return fail(DVQ_ELAUNCH, "vq_argmin: cannot initialise the index buffer");
+            hipLaunchKernelGGL((vq_argmin_generic_kernel<DT, 1, true>), dim3((unsigned)groups, (unsigned)split), dim3(64), 0, st,
+                               reinterpret_cast<const typename VqTraits<DT>::elem*>(z), ws, reinterpret_cast<const float*>(ws + p.e2_off),
+                               n, D, p.n_tiles, idx_out);
+            hipLaunchKernelGGL(vq_unpack_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx_out, n);
+            return check_launch("vq_argmin(generic, split)");
+        }
+        hipLaunchKernelGGL((vq_argmin_generic_kernel<DT, 1>), dim3((unsigned)groups), dim3(64), 0, st,
+                           reinterpret_cast<const typename VqTraits<DT>::elem*>(z), ws, reinterpret_cast<const float*>(ws + p.e2_off),
+                           n, D, p.n_tiles, idx_out);
+        return check_launch("vq_argmin(generic)");
     }
     constexpr int WAVES = 4;
     const int64_t groups = (n + WAVES * 32 - 1) / (WAVES * 32);

@@ -51,6 +51,20 @@ def test_vq_ragged_sizes(n, dtype):
         check_vq_rows(z.float(), E.float(), idx.cpu().numpy(), ref[:, 0].numpy())
 
 
+@pytest.mark.parametrize("n", [37, 40000])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vq_wide_rows_generic_kernel(n, dtype):
+    """Row widths without a specialised kernel (the 1024-wide object codebook, and a width of 48): few latents take
+    the variant that spreads the code tiles over workgroups and merges with 64-bit atomics, many the plain one."""
+    for K, D in ((100, 1024), (70, 48)):
+        z, E = synth.vq_case(K, D, n, "B", seed=11)
+        z, E = z.to(dtype), E.to(dtype)
+        idx, _ = ops.vq_argmin(z.to(DEV), E.to(DEV), want_zq=False)
+        ref, _ = O.vq_forward(z.float(), E.float())
+        assert int(idx.max()) < K and int(idx.min()) >= 0
+        check_vq_rows(z.float(), E.float(), idx.cpu().numpy(), ref[:, 0].numpy())
+
+
 def test_vq_ties_pick_lowest_index_and_odd_K():
     g = load_golden("vq")
     z, E = synth.vq_case(128, 256, 37, "A", seed=3)

@@ -63,6 +63,17 @@ def vq():
             del z, E, ws
 
 
+def vq_obj():
+    """The object codebook search as gen() runs it: one 1024-d row per object, 128 codes, fp32."""
+    for n in (4096, 256, 1):
+        g = torch.Generator(dev).manual_seed(1)
+        E = torch.randn(128, 1024, device=dev, generator=g)
+        z = torch.randn(n, 1024, device=dev, generator=g)
+        ws = ops.vq_prepare(E)
+        ms = timeit(lambda: ops.vq_argmin(z, E, want_zq=False, prepared=ws), iters=10)
+        print(f"vq_argmin K=128 D=1024 n={n} fp32: {ms * 1e3:8.1f} us", flush=True)
+
+
 def mano():
     import mano as M
     from dvq_hip.mano_io import Struct
