@@ -26,6 +26,8 @@
 // input cloud once (16 B per point) and 4 KiB of output per cloud.
 #include "common.h"
 
+#include <type_traits>
+
 namespace dvq {
 
 constexpr int kPnWaves = 8;
@@ -273,15 +275,24 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
         // ---- conv1 + conv2 for this wave's NP point tiles -> X (conv3 A fragments)
         bf16x8 Xb[(DT == DVQ_BF16) ? NP : 1][8];
         float Xf[(DT == DVQ_F32) ? NP : 1][64];
+        // Tiles of 32 points are dealt to the waves round-robin (tile = chunk*wpc*NP + np*wpc + lw), so in the last
+        // chunk of a cloud the tiles past its end fall into the higher np slots of most waves and are skipped
+        // outright: nv = this wave's tiles that hold at least one point.
+        const int tile0 = chunk * (wpc * NP) + lw;
+        const int n_tiles_cloud = (N + 31) / 32;
+        int nv = 0;
+#pragma unroll
+        for (int np = 0; np < NP; ++np) nv += (tile0 + np * wpc < n_tiles_cloud) ? 1 : 0;
         {
-            const int nbase = chunk * PTS_PER_CHUNK + lw * NP * 32 + r;
             // one call per point tile, spelled out so that every fragment index is a constant
 #define DVQ_PN_TILE(np)                                                                                           \
     if constexpr (NP > np) {                                                                                      \
-        int n = nbase + np * 32;                                                                                  \
-        if (n >= N) n = N - 1; /* duplicate the last point: a duplicate cannot change a max */                    \
-        pn_point_tile<DT, C>(xb, N, n, has_trans, T, a1s, c1s, a2s, c2s, lane, h, Xb[(DT == DVQ_BF16) ? np : 0],  \
-                             Xf[(DT == DVQ_F32) ? np : 0]);                                                       \
+        if (np < nv) {                                                                                            \
+            int n = (tile0 + np * wpc) * 32 + r;                                                                  \
+            if (n >= N) n = N - 1; /* duplicate the last point: a duplicate cannot change a max */                \
+            pn_point_tile<DT, C>(xb, N, n, has_trans, T, a1s, c1s, a2s, c2s, lane, h, Xb[(DT == DVQ_BF16) ? np : 0], \
+                                 Xf[(DT == DVQ_F32) ? np : 0]);                                                   \
+        }                                                                                                         \
     }
             DVQ_PN_TILE(0) DVQ_PN_TILE(1) DVQ_PN_TILE(2) DVQ_PN_TILE(3)
 #undef DVQ_PN_TILE
@@ -299,11 +310,12 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
                 for (int u = wave; u < UNITS; u += kPnWaves) glds16(src + (int64_t)u * 1024 + lane * 16, dst + u * 1024);
             }
             const char* sb = w3s + buf * STAGE_BYTES + lane * 16;
-#pragma unroll 1
-            for (int cc = 0; cc < Cfg::CPS; ++cc) {
-                f32x16 acc[NP];
+            // conv3 of one channel tile for the first NV point tiles of this wave
+            auto conv3_tile = [&](auto nvc, int cc) {
+                constexpr int NV = decltype(nvc)::value;
+                f32x16 acc[NV];
 #pragma unroll
-                for (int np = 0; np < NP; ++np)
+                for (int np = 0; np < NV; ++np)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[np][i] = 0.f;
 #pragma unroll
@@ -311,24 +323,32 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
                     if constexpr (DT == DVQ_BF16) {
                         const bf16x8 w = *reinterpret_cast<const bf16x8*>(sb + (cc * Cfg::UPC + u) * 1024);
 #pragma unroll
-                        for (int np = 0; np < NP; ++np)
+                        for (int np = 0; np < NV; ++np)
                             acc[np] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xb[np][u], w, acc[np], 0, 0, 0);
                     } else {
                         const f32x4 w = *reinterpret_cast<const f32x4*>(sb + (cc * Cfg::UPC + u) * 1024);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
 #pragma unroll
-                            for (int np = 0; np < NP; ++np)
+                            for (int np = 0; np < NV; ++np)
                                 acc[np] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xf[np][4 * u + q], w[q], acc[np], 0, 0, 0);
                     }
                 }
                 float m = acc[0][0];
 #pragma unroll
-                for (int np = 0; np < NP; ++np)
+                for (int np = 0; np < NV; ++np)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[np][i]);
                 m = fmaxf(m, __shfl_xor(m, 32, 64));
                 if (h == 0) atomicMax(&wmax[(st * Cfg::CPS + cc) * 32 + r], f32_key(m));
+            };
+            static_assert(NP == 2, "the dispatch below spells out NP = 2");
+            if (nv == 2) {
+#pragma unroll 1
+                for (int cc = 0; cc < Cfg::CPS; ++cc) conv3_tile(std::integral_constant<int, 2>{}, cc);
+            } else if (nv == 1) {
+#pragma unroll 1
+                for (int cc = 0; cc < Cfg::CPS; ++cc) conv3_tile(std::integral_constant<int, 1>{}, cc);
             }
             __syncthreads();  // next stage landed; this buffer is free for the stage after
         }
