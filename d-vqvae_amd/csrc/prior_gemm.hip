@@ -300,6 +300,146 @@ __global__ void prior_embed_kernel(const int64_t* __restrict__ idx, int64_t idx_
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// Vertical stack of one grid row in one launch (kernel-3 layers): the three cells of the row read the same input
+// activations (cell j takes column c of input row r through tap db = c - j) and every tap matrix serves two or three
+// cells, so a workgroup that owns a 128-sample x 128-feature tile of ALL THREE cells loads each activation unit
+// and each weight unit once per k-block instead of once per cell: 149 FLOP per byte moved from L2 against 64 for
+// the per-cell product above, which is what bounds it.  Stage = one input row x one k-block: 3 columns of
+// activations (2 units per wave each) + 3 taps of weights (NO x 2 units each), 48 KiB, ring of three.
+struct PvDesc {
+    const char* x[2][3];
+    const char* w[2][3];
+    int n_rows;
+    int kb;
+    const float* bias;
+    const float* cond;
+    const int64_t* label;
+    char* out_packed[3];
+    char* out_pre[3];
+};
+
+__global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int M, int N) {
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NO = 4;
+    constexpr int W_UNITS = 3 * NO * 2;                      // [tap][t][q]
+    constexpr int X_UNITS = 3 * kPgWaves * 2;                // [col][wave][q]
+    constexpr int STAGE_BYTES = (W_UNITS + X_UNITS) * 1024;
+    constexpr int R = kPgRing;
+    constexpr int GLDS_PER_STAGE = W_UNITS / kPgWaves + 6;   // per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int SB = (M + 31) / 32;
+    const int n_ob = N / 32, half = n_ob / 2;
+    int ob[NO];
+#pragma unroll
+    for (int t = 0; t < NO / 2; ++t) { ob[t] = (NO / 2) * blockIdx.x + t; ob[t + NO / 2] = half + (NO / 2) * blockIdx.x + t; }
+    int sb = blockIdx.y * kPgWaves + wave;
+    const bool live = sb < SB;
+    if (!live) sb = SB - 1;
+    const int KB = d.kb;
+
+    f32x16 acc[3][NO];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int t = 0; t < NO; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.f;
+
+    const int total_stages = d.n_rows * KB;
+    auto issue = [&](int st) {
+        const int row = st / KB, kb0 = st - row * KB;
+        char* dst = smem + (st % R) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < W_UNITS / kPgWaves; ++i) {
+            const int u = wave + kPgWaves * i;               // u = (tap * NO + t) * 2 + q
+            const int tap = u / (NO * 2), t = (u / 2) % NO, q = u & 1;
+            pg_glds16(d.w[row][tap] + ((int64_t)(ob[t] * KB + kb0) * 2 + q) * 1024 + lane * 16, dst + u * 1024);
+        }
+#pragma unroll
+        for (int col = 0; col < 3; ++col)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                pg_glds16(d.x[row][col] + (((int64_t)kb0 * SB + sb) * 2 + q) * 1024 + lane * 16,
+                          dst + (W_UNITS + (col * kPgWaves + wave) * 2 + q) * 1024);
+    };
+
+    int issued = 0;
+    for (; issued < R - 1 && issued < total_stages; ++issued) issue(issued);
+    for (int st = 0; st < total_stages; ++st) {
+        if (issued - st - 1 >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(GLDS_PER_STAGE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (issued < total_stages) { issue(issued); ++issued; }
+        const char* sbuf = smem + (st % R) * STAGE_BYTES + lane * 16;
+        // 2 x 12 weight fragments per stage, each feeding two or three MFMAs; a fragment is read one item ahead of
+        // its use so that the LDS traffic (30 KiB per wave and stage) runs under the matrix pipe, not before it
+        auto xaddr = [&](int q, int col) { return sbuf + (W_UNITS + (col * kPgWaves + wave) * 2 + q) * 1024; };
+        auto waddr = [&](int item) {   // item = q * 12 + tap * NO + t
+            const int q = item / (3 * NO), r = item % (3 * NO);
+            return sbuf + (r * 2 + q) * 1024;
+        };
+        bf16x8 xf[3], wq[2];
+#pragma unroll
+        for (int col = 0; col < 3; ++col) xf[col] = *reinterpret_cast<const bf16x8*>(xaddr(0, col));
+        wq[0] = *reinterpret_cast<const bf16x8*>(waddr(0));
+#pragma unroll
+        for (int item = 0; item < 2 * 3 * NO; ++item) {
+            const int q = item / (3 * NO), tap = (item % (3 * NO)) / NO, t = item % NO;
+            if (item + 1 < 2 * 3 * NO) wq[(item + 1) & 1] = *reinterpret_cast<const bf16x8*>(waddr(item + 1));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int col = j + tap - 1;       // tap <-> column offset tap - 1: cell j reads column j + tap - 1
+                if (col >= 0 && col < 3) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[item & 1], xf[col], acc[j][t], 0, 0, 0);
+            }
+            if (item == 3 * NO - 1) {              // last item of q = 0: its activations are dead, fetch those of q = 1
+#pragma unroll
+                for (int col = 0; col < 3; ++col) xf[col] = *reinterpret_cast<const bf16x8*>(xaddr(1, col));
+            }
+            (void)q;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    if (!live) return;
+    int m = sb * 32 + c;
+    if (m >= M) m = M - 1;
+    const float* crow = d.cond + d.label[m] * N;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int t = 0; t < NO / 2; ++t) {
+            float g[16], pre_lo[16], pre_hi[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int nlo = 32 * ob[t] + 8 * q4 + 4 * h, nhi = 32 * ob[t + NO / 2] + 8 * q4 + 4 * h;
+                const f32x4 blo = *reinterpret_cast<const f32x4*>(d.bias + nlo);
+                const f32x4 bhi = *reinterpret_cast<const f32x4*>(d.bias + nhi);
+                const f32x4 clo = *reinterpret_cast<const f32x4*>(crow + nlo);
+                const f32x4 chi = *reinterpret_cast<const f32x4*>(crow + nhi);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * q4 + q;
+                    pre_lo[i] = acc[j][t][i] + blo[q];
+                    pre_hi[i] = acc[j][t + NO / 2][i] + bhi[q];
+                    g[i] = fast_tanh(pre_lo[i] + clo[q]) * fast_sigmoid(pre_hi[i] + chi[q]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                *reinterpret_cast<uint4*>(d.out_packed[j] + (((int64_t)ob[t] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(g + 8 * s2);
+                if (d.out_pre[j]) {
+                    *reinterpret_cast<uint4*>(d.out_pre[j] + (((int64_t)ob[t] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(pre_lo + 8 * s2);
+                    *reinterpret_cast<uint4*>(d.out_pre[j] + (((int64_t)ob[t + NO / 2] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(pre_hi + 8 * s2);
+                }
+            }
+        }
+    }
+}
+
 // One grid cell of the sampling loop in a single launch (DVQ-VAE/network/pixelcnn/models.py:189-196): softmax of the
 // logits row, renormalisation, inverse-CDF draw with the row's uniform u in [0,1), the index written into the grid and
 // its embedding row written as the packed input of the next cell.  One wave per row; lane l owns classes
@@ -410,6 +550,32 @@ extern "C" int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const flo
     hipLaunchKernelGGL(prior_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), idx, idx_stride, table, V, M, d,
                        reinterpret_cast<uint4*>(out));
     return check_launch("prior_embed");
+}
+
+extern "C" int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream) {
+    if (!v || M < 1) return fail(DVQ_EINVAL, "prior_vrow: bad arguments");
+    if (N < 256 || (N % 256) != 0) return fail(DVQ_EINVAL, "prior_vrow: N must be a multiple of 256 (got %d)", N);
+    if (v->n_rows < 1 || v->n_rows > 2 || v->k_blocks < 1) return fail(DVQ_EINVAL, "prior_vrow: 1 or 2 input rows, k_blocks >= 1");
+    if (!v->bias || !v->cond || !v->label) return fail(DVQ_EINVAL, "prior_vrow: bias, cond and label are required");
+    PvDesc d;
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c) {
+            if (r < v->n_rows && (!v->x[r][c] || !v->w[r][c])) return fail(DVQ_EINVAL, "prior_vrow: null operand (row %d, column %d)", r, c);
+            d.x[r][c] = reinterpret_cast<const char*>(v->x[r][c]);
+            d.w[r][c] = reinterpret_cast<const char*>(v->w[r][c]);
+        }
+    for (int j = 0; j < 3; ++j) {
+        if (!v->out_packed[j]) return fail(DVQ_EINVAL, "prior_vrow: out_packed[%d] missing", j);
+        d.out_packed[j] = reinterpret_cast<char*>(v->out_packed[j]);
+        d.out_pre[j] = reinterpret_cast<char*>(v->out_pre[j]);
+    }
+    d.n_rows = v->n_rows; d.kb = v->k_blocks; d.bias = v->bias; d.cond = v->cond; d.label = v->label;
+    const int SB = (M + 31) / 32;
+    const dim3 grid(N / 128, (SB + kPgWaves - 1) / kPgWaves);
+    const size_t lds = (size_t)kPgRing * (3 * 4 * 2 + 3 * kPgWaves * 2) * 1024;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_vrow_kernel), lds, "prior_vrow")) return rc;
+    hipLaunchKernelGGL(prior_vrow_kernel, grid, dim3(kPgWaves * 64), lds, as_stream(stream), d, M, N);
+    return check_launch("prior_vrow");
 }
 
 extern "C" int dvq_prior_sample(const float* logits, int n_classes, int M, const double* u, int64_t u_stride, int64_t* x_out,

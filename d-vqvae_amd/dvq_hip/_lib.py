@@ -43,6 +43,12 @@ class DvqPriorJob(ctypes.Structure):
                 ("out_rows", c_void_p)]
 
 
+class DvqPriorVRow(ctypes.Structure):
+    _fields_ = [("x", (c_void_p * 3) * 2), ("w", (c_void_p * 3) * 2), ("n_rows", c_int), ("k_blocks", c_int),
+                ("bias", c_void_p), ("cond", c_void_p), ("label", c_void_p), ("out_packed", c_void_p * 3),
+                ("out_pre", c_void_p * 3)]
+
+
 # name -> (restype, argtypes); mirrors include/dvq_hip.h one to one
 SIGNATURES = {
     "dvq_version": (c_int, []),
@@ -61,6 +67,7 @@ SIGNATURES = {
     "dvq_prior_pack_weight": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_gemm": (c_int, [POINTER(DvqPriorJob), c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dvq_prior_vrow": (c_int, [POINTER(DvqPriorVRow), c_int, c_int, c_void_p]),
     "dvq_prior_sample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p]),

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import DVQ_BF16, DVQ_F32, DvqHandMesh, DvqManoConsts, DvqPointMlp, DvqPriorJob
+from ._lib import DVQ_BF16, DVQ_F32, DvqHandMesh, DvqManoConsts, DvqPointMlp, DvqPriorJob, DvqPriorVRow
 
 
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
@@ -338,3 +338,24 @@ def prior_sample(logits: torch.Tensor, u: torch.Tensor, x_out: torch.Tensor, tab
         rc = _lib.load().dvq_prior_sample(_p(logits), n, M, _p(u), u.stride(0), _p(x_out), x_out.stride(0), _p(table),
                                           0 if table is None else table.shape[1], _p(emb_out), _stream(logits))
     _lib.check(rc, "dvq_prior_sample")
+
+
+def prior_vrow(rows, k_blocks: int, bias, cond, label, out_packed, out_pre, M: int, N: int) -> None:
+    """Vertical stack of one grid row.  rows: 1 or 2 entries (xs, ws) with xs = the three packed input columns of
+    that input row and ws = the packed tap weights for column offsets -1, 0, +1; out_packed / out_pre: three
+    packed outputs each (out_pre entries may be None)."""
+    v = DvqPriorVRow()
+    v.n_rows, v.k_blocks = len(rows), k_blocks
+    keep = []
+    for r, (xs, ws) in enumerate(rows):
+        for c in range(3):
+            _need_gpu(xs[c], ws[c])
+            v.x[r][c], v.w[r][c] = xs[c].data_ptr(), ws[c].data_ptr()
+            keep += [xs[c], ws[c]]
+    v.bias, v.cond, v.label = bias.data_ptr(), cond.data_ptr(), label.data_ptr()
+    for j in range(3):
+        v.out_packed[j] = out_packed[j].data_ptr()
+        v.out_pre[j] = out_pre[j].data_ptr() if out_pre[j] is not None else None
+    with torch.cuda.device(bias.device):
+        rc = _lib.load().dvq_prior_vrow(ctypes.byref(v), M, N, _stream(bias))
+    _lib.check(rc, "dvq_prior_vrow")

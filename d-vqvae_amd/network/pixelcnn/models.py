@@ -125,6 +125,8 @@ class _PackedTaps:
         self.resid_bias = layer.horiz_resid.bias.detach().float().contiguous()
         self.cond = layer.class_cond_embedding.weight.detach().float().contiguous()
         self.residual = layer.residual
+        self.kernel = k
+        self.mask_a = layer.mask_type == 'A'
 
 
 class GatedPixelCNN(nn.Module):
@@ -237,6 +239,13 @@ class GatedPixelCNN(nn.Module):
         probs_all = []
         for i in range(H):
             for l, t in enumerate(layers):
+                if W == 3 and t.kernel == 3 and not t.mask_a and B >= 3072:   # smaller batches are latency-bound: per-cell launches
+                    # all three cells of the row in one launch: every input column and every tap is fetched once
+                    rows = [([XV[l][i + da][c] for c in range(3)], [t.vert[(da, db)] for db in (-1, 0, 1)])
+                            for da in (-1, 0) if i + da >= 0]
+                    ops.prior_vrow(rows, kb, t.vert_bias, t.cond, label, [XV[l + 1][i][j] for j in range(3)],
+                                   [HV[l][j] for j in range(3)], B, 2 * d)
+                    continue
                 jobs = []
                 for j in range(W):
                     taps = [(XV[l][i + da][j + db], w, kb) for (da, db), w in t.vert.items()

@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 102   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 103   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -227,6 +227,23 @@ int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K
 /* out(packed)[m] = table[idx[m*idx_stride]]: embedding rows of sampled indices, d features */
 int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, void* out, void* stream);
 int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, void* stream);
+/* Vertical stack of one grid row of a kernel-3 layer (models.py:72-73 for the three cells of a row at once):
+ *   y_j = bias + sum over input rows r and columns c with |c - j| <= 1 of  w[r][c - j + 1] * x[r][c],   j = 0, 1, 2
+ * followed by the GATE epilogue of dvq_prior_gemm per cell (out_packed[j]: N/2 features; out_pre[j], optional: N).
+ * Same numbers as three dvq_prior_gemm jobs; each activation and weight unit is fetched once for all three cells. */
+typedef struct {
+    const void* x[2][3];     /* packed activations of input row r, grid column c (32*k_blocks features) */
+    const void* w[2][3];     /* packed weights [N, 32*k_blocks] of tap (row r, column offset -1, 0, +1) */
+    int n_rows;              /* 1 or 2 input rows                                                       */
+    int k_blocks;
+    const float* bias;       /* [N]            */
+    const float* cond;       /* [n_classes, N] */
+    const int64_t* label;    /* [M]            */
+    void* out_packed[3];
+    void* out_pre[3];
+} DvqPriorVRow;
+int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream);
+
 /* One cell of the sampling loop (models.py:189-196): p = softmax(logits[m, :]) / sum, x = inverse CDF of p at the
  * uniform u[m*u_stride] in [0,1) (fp64 running sum; the number of cdf entries <= u, clamped to n_classes-1), written to
  * x_out[m*x_stride]; if emb_out is given, row x of `table` [n_classes, d] is also written there as packed activations

@@ -124,6 +124,38 @@ def test_prior_bf16_kernels_vs_fp32():
     assert torch.equal(x16c[0], x16[40])       # and of batch size, down to one
 
 
+def test_prior_vrow_kernel_equals_three_per_cell_products():
+    """The fused row kernel against three dvq_prior_gemm jobs on the same operands: same taps, another summation
+    order, so the packed bf16 results may differ by an ulp of bf16 (2^-8 relative) and no more."""
+    from dvq_hip import ops
+    g = torch.Generator(DEV).manual_seed(6)
+    d, N, n_cls = 128, 256, 16
+    for M, n_rows in ((100, 2), (4096, 2), (64, 1)):
+        label = torch.randint(0, n_cls, (M,), device=DEV, generator=g)
+        bias = torch.randn(N, device=DEV, generator=g) * 0.1
+        cond = torch.randn(n_cls, N, device=DEV, generator=g) * 0.1
+        xs = [[ops.prior_packed_empty(M, d, DEV, True) for _ in range(3)] for _ in range(n_rows)]
+        tab = torch.randn(50, d, device=DEV, generator=g)
+        for r in range(n_rows):
+            for c in range(3):
+                ops.prior_embed(torch.randint(0, 50, (M,), device=DEV, generator=g), tab, xs[r][c])
+        ws = [[ops.prior_pack_weight(torch.randn(N, d, device=DEV, generator=g) * 0.05) for _ in range(3)] for _ in range(n_rows)]
+        outs = [[ops.prior_packed_empty(M, N // 2, DEV, True) for _ in range(3)] for _ in range(2)]
+        pres = [[ops.prior_packed_empty(M, N, DEV, True) for _ in range(3)] for _ in range(2)]
+        ops.prior_vrow([(xs[r], ws[r]) for r in range(n_rows)], d // 32, bias, cond, label, outs[0], pres[0], M, N)
+        jobs = []
+        for j in range(3):
+            taps = [(xs[r][c], ws[r][c - j + 1], d // 32) for r in range(n_rows) for c in range(3) if abs(c - j) <= 1]
+            jobs.append(ops.prior_job(taps, bias, cond=cond, label=label, out_packed=outs[1][j], out_pre=pres[1][j]))
+        ops.prior_gemm(jobs, M, N, ops.PRIOR_GATE, False, bias)
+        for a, b in zip(outs[0] + pres[0], outs[1] + pres[1]):
+            fa = a.view(torch.bfloat16).float()
+            fb = b.view(torch.bfloat16).float()
+            assert torch.isfinite(fa).all()
+            assert (fa - fb).abs().max().item() <= 2.0 ** -7 * fb.abs().max().item()
+            assert (fa != fb).float().mean().item() < 0.05
+
+
 def test_prior_sample_kernel_equals_softmax_cumsum_searchsorted():
     """The fused cell sampler against the torch formulation it replaces (softmax, renormalise, fp64 cumulative
     sum, searchsorted) and against prior_embed for the packed embedding rows."""
