@@ -54,9 +54,11 @@ def test_vq_ragged_sizes(n, dtype):
 @pytest.mark.parametrize("n", [37, 40000])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_vq_wide_rows_generic_kernel(n, dtype):
-    """Row widths without a specialised kernel (the 1024-wide object codebook, and a width of 48): few latents take
-    the variant that spreads the code tiles over workgroups and merges with 64-bit atomics, many the plain one."""
-    for K, D in ((100, 1024), (70, 48)):
+    """Row widths beyond the register kernels (the 1024-wide object codebook, 512, 384 and a width of 48): few latents
+    take the variant that spreads the code tiles over workgroups and merges with 64-bit atomics; many take the chunked
+    wide-row kernel when the width is a whole number of chunks (256 bf16 / 128 fp32 dims; 300 and 200 codes make
+    several code groups with a partial last one) and the plain generic kernel otherwise."""
+    for K, D in ((100, 1024), (70, 48), (300, 512), (200, 384)):
         z, E = synth.vq_case(K, D, n, "B", seed=11)
         z, E = z.to(dtype), E.to(dtype)
         idx, _ = ops.vq_argmin(z.to(DEV), E.to(DEV), want_zq=False)
@@ -115,6 +117,35 @@ def test_vq_full_size_properties():
     zb = z.to(torch.bfloat16)
     idx_b, _ = ops.vq_argmin(zb, Ed.to(torch.bfloat16), want_zq=False)
     assert (idx_b.cpu() == j).float().mean().item() > 0.9999
+
+
+@pytest.mark.parametrize("K", [256, 320, 512, 1000, 2048])
+def test_vq_bf16_long_codebook_rotating_sweep(K):
+    """Many latents against a long bf16 codebook take the kernel whose latent tiles start their sweep at different
+    quarters of the codebook.  Its result must equal, bit for bit, that of the one-sweep kernel (taken by slices below
+    65536 rows): every score is the same chain of operations, and equal scores -- planted here as duplicated codes in
+    different quarters, and latents equal to them -- still go to the lowest index.  One slice is checked against the
+    oracle as well."""
+    n = 65536 * 2 + 16 * 37 + 5                   # ragged: the last tile is partial, waves hold different tile counts
+    z, E = synth.vq_case(K, 256, n, "B", seed=21)
+    dup = [(3, K - 2), (K // 4 + 1, K // 2 + 7), (K // 2 - 1, 3 * K // 4 + 5), (40, K // 4 + 40)]
+    for lo, hi in dup:
+        E[hi] = E[lo]
+    for t, (lo, hi) in enumerate(dup):
+        z[t::97][:200] = E[hi] + 0.01 * torch.randn(200, 256, generator=torch.Generator().manual_seed(t))
+        z[50 + t] = E[hi]
+    zb, Eb = z.to(torch.bfloat16).to(DEV), E.to(torch.bfloat16).to(DEV)
+    ws = ops.vq_prepare(Eb)
+    idx, _ = ops.vq_argmin(zb, Eb, want_zq=False, prepared=ws)
+    parts = [ops.vq_argmin(zb[i:i + 50000].contiguous(), Eb, want_zq=False, prepared=ws)[0] for i in range(0, n, 50000)]
+    assert torch.equal(idx, torch.cat(parts))
+    his = torch.tensor([hi for _, hi in dup], device=DEV)
+    assert not torch.isin(idx, his).any()         # a duplicate's higher index never wins
+    for t, (lo, hi) in enumerate(dup):
+        assert idx[50 + t].item() == lo
+    sl = slice(n - 3000, n)
+    ref, _ = O.vq_forward(zb[sl].float().cpu(), Eb.float().cpu())
+    check_vq_rows(zb[sl].float().cpu(), Eb.float().cpu(), idx[sl].cpu().numpy(), ref[:, 0].numpy())
 
 
 def test_errors_are_raised_not_fatal():

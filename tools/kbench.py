@@ -48,7 +48,7 @@ def pointnet():
 def vq():
     n = 1 << 20
     for dt, name, peak in ((torch.bfloat16, "bf16", 2500.0), (torch.float32, "fp32", 157.3)):
-        for K, D in ((128, 256), (512, 256), (2048, 256), (8192, 256), (128, 1024)):
+        for K, D in ((128, 256), (256, 256), (512, 256), (1024, 256), (2048, 256), (8192, 256), (128, 1024)):
             nn = n if D == 256 else n // 4
             g = torch.Generator(dev).manual_seed(K)
             E = torch.randn(K, D, device=dev, generator=g)
