@@ -137,6 +137,14 @@ def gen():
             print(f"generate B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  {B / ms * 1e3:10.0f} grasps/s", flush=True)
 
 
+def gen4096():
+    from dvq_hip.pipeline import GraspGenerator
+    g = GraspGenerator.synthetic(dev, seed=0, dtype=torch.bfloat16)
+    obj = synth.object_clouds_device(4096, 3000, 11, dev)
+    ms = timeit(lambda: g.generate(obj), iters=10, warm=3)
+    print(f"generate B=4096 bf16: {ms:8.3f} ms  {4096 / ms * 1e3:10.0f} grasps/s", flush=True)
+
+
 def tta():
     import mano as M
     from dvq_hip.mano_io import Struct
