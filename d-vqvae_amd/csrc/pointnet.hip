@@ -19,11 +19,14 @@
 //                         two half-waves and one LDS atomic per (wave, 32 channels)
 //                         folds it into the block's running maximum.
 //
-// One workgroup (8 waves) walks one cloud in chunks of 8*NP*32 points.  The conv3
+// One workgroup (8 waves) walks one cloud in chunks of 512 points.  The conv3
 // weights (256 KiB bf16 / 512 KiB fp32, pre-packed in fragment order) stream through a
 // double-buffered LDS stage by direct global->LDS loads while the matrix cores work on
 // the previous stage; conv1/conv2 weights stay resident in LDS.  HBM traffic is the
 // input cloud once (16 B per point) and 4 KiB of output per cloud.
+//
+// Two kernels: fp32 on the 32x32x2 MFMA (the description above, literally) and bf16 on the
+// 16x16x32 MFMA (same fusion on 16-point tiles; its lane mapping is described at the kernel).
 #include "common.h"
 
 #include <type_traits>
@@ -36,14 +39,6 @@ constexpr int kC1 = 64, kC2 = 128, kC3 = 1024;
 constexpr int kCt = kC3 / 32;  // 32 output-channel tiles
 
 template <int DT> struct PnCfg;
-template <> struct PnCfg<DVQ_BF16> {
-    static constexpr int NP = 2;          // 32-point tiles per wave and chunk
-    static constexpr int UPC = 8;         // 1-KiB conv3 weight units per channel tile (4 row tiles x 2 k-steps)
-    static constexpr int CPS = 2;         // channel tiles per LDS stage (16 KiB): 54 KiB of LDS, two blocks per CU
-    static constexpr int MIN_WAVES = 4;   // waves per SIMD to aim the register allocation at
-    static constexpr int A2_UNITS = 16;   // conv2 weights: 4 row tiles x 4 k-steps
-    static constexpr int XR = 8;          // 4-register groups of conv2 output per point tile (8 frags x 4 VGPRs)
-};
 template <> struct PnCfg<DVQ_F32> {
     static constexpr int NP = 2;
     static constexpr int UPC = 16;        // 4 row tiles x 4 groups of 4 k-steps
@@ -68,9 +63,8 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_bas
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// conv3 weights [1024,128] fp32 -> fragment order for `DT`.
-//   bf16 unit (ct, t2, s): lane (c,h) holds 8 bf16: j -> A3[32ct+c][32t2 + 16s + 8(j>>2) + 4h + (j&3)]
-//   fp32 unit (ct, t2, g): lane (c,h) holds 4 f32 : q -> A3[32ct+c][32t2 + 8g + 4h + q]
+// conv3 weights [1024,128] fp32 -> fragment order of the fp32 kernel.
+//   unit (ct, t2, g): lane (c,h) holds 4 f32 : q -> A3[32ct+c][32t2 + 8g + 4h + q]
 // (the k order an accumulator tile presents when it is reused as an MFMA A operand).
 template <int DT>
 __global__ void pn_pack_w3_kernel(const float* __restrict__ a3, uint4* __restrict__ out) {
@@ -82,13 +76,7 @@ __global__ void pn_pack_w3_kernel(const float* __restrict__ a3, uint4* __restric
     const int ct = unit / PnCfg<DT>::UPC, u = unit % PnCfg<DT>::UPC;
     const float* row = a3 + (ct * 32 + c) * kC2;
     uint4 v;
-    if (DT == DVQ_BF16) {
-        const int t2 = u >> 1, s = u & 1;
-        unsigned short e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16_bits(row[32 * t2 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)]);
-        v.x = e[0] | (e[1] << 16); v.y = e[2] | (e[3] << 16); v.z = e[4] | (e[5] << 16); v.w = e[6] | (e[7] << 16);
-    } else {
+    {
         const int t2 = u >> 2, g = u & 3;
         v = *reinterpret_cast<const uint4*>(row + 32 * t2 + 8 * g + 4 * h);
     }
@@ -96,12 +84,11 @@ __global__ void pn_pack_w3_kernel(const float* __restrict__ a3, uint4* __restric
 }
 
 // conv1 (VALU) + conv2 (MFMA) for one tile of 32 points: lane (r,h) owns point `n`.
-// Leaves relu(conv2) in `xb` (bf16, 8 A-operand fragments) or `xf` (fp32, 64 values) in the
-// k order conv3 consumes.
+// Leaves relu(conv2) in `Xf_np` (64 values) in the k order conv3 consumes.
 template <int DT, int C>
 __device__ __forceinline__ void pn_point_tile(const float* __restrict__ xb_, int N, int n, bool has_trans, const float (&T)[9],
                                               const float* a1s, const float* c1s, const char* a2s, const float* c2s,
-                                              int lane, int h, bf16x8 (&Xb_np)[8], float (&Xf_np)[64]) {
+                                              int lane, int h, float (&Xf_np)[64]) {
     const float* xb = xb_;
     float p[4];
 #pragma unroll
@@ -130,39 +117,7 @@ __device__ __forceinline__ void pn_point_tile(const float* __restrict__ xb_, int
             o[q] = v > 0.f ? v : 0.f;
         }
     };
-    if constexpr (DT == DVQ_BF16) {
-        bf16x8 hb[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float lo[4], hi[4];
-            conv1_4(2 * s, lo);
-            conv1_4(2 * s + 1, hi);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { hb[s][j] = static_cast<__bf16>(lo[j]); hb[s][4 + j] = static_cast<__bf16>(hi[j]); }
-        }
-#pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) {
-            f32x16 acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(c2s + 32 * t2 + 8 * g + 4 * h);
-                acc[4 * g + 0] = bias[0]; acc[4 * g + 1] = bias[1]; acc[4 * g + 2] = bias[2]; acc[4 * g + 3] = bias[3];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(a2s + ((t2 * 4 + s) * 64 + lane) * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = acc[8 * s + j];
-                    Xb_np[t2 * 2 + s][j] = static_cast<__bf16>(v > 0.f ? v : 0.f);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
+    {
         float h1[32];
 #pragma unroll
         for (int t4 = 0; t4 < 8; ++t4) {
@@ -242,16 +197,7 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
     for (int i = tid; i < Cfg::A2_UNITS * 64; i += kPnThreads) {
         const int l = i & 63, u = i >> 6;
         const int rr = l & 31, hh = l >> 5;
-        if (DT == DVQ_BF16) {
-            const int t2 = u >> 2, s = u & 3;
-            const float* src = a2 + (32 * t2 + rr) * kC1 + 32 * hh + 8 * s;
-            unsigned short e[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16_bits(src[j]);
-            uint4 v;
-            v.x = e[0] | (e[1] << 16); v.y = e[2] | (e[3] << 16); v.z = e[4] | (e[5] << 16); v.w = e[6] | (e[7] << 16);
-            *reinterpret_cast<uint4*>(a2s + i * 16) = v;
-        } else {
+        {
             const int t2 = u >> 3, t4 = u & 7;
             *reinterpret_cast<uint4*>(a2s + i * 16) =
                 *reinterpret_cast<const uint4*>(a2 + (32 * t2 + rr) * kC1 + 32 * hh + 4 * t4);
@@ -273,8 +219,7 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
             for (int u = wave; u < UNITS; u += kPnWaves) glds16(w3p + (int64_t)u * 1024 + lane * 16, w3s + u * 1024);
         }
         // ---- conv1 + conv2 for this wave's NP point tiles -> X (conv3 A fragments)
-        bf16x8 Xb[(DT == DVQ_BF16) ? NP : 1][8];
-        float Xf[(DT == DVQ_F32) ? NP : 1][64];
+        float Xf[NP][64];
         // Tiles of 32 points are dealt to the waves round-robin (tile = chunk*wpc*NP + np*wpc + lw), so in the last
         // chunk of a cloud the tiles past its end fall into the higher np slots of most waves and are skipped
         // outright: nv = this wave's tiles that hold at least one point.
@@ -290,8 +235,7 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
         if (np < nv) {                                                                                            \
             int n = (tile0 + np * wpc) * 32 + r;                                                                  \
             if (n >= N) n = N - 1; /* duplicate the last point: a duplicate cannot change a max */                \
-            pn_point_tile<DT, C>(xb, N, n, has_trans, T, a1s, c1s, a2s, c2s, lane, h, Xb[(DT == DVQ_BF16) ? np : 0], \
-                                 Xf[(DT == DVQ_F32) ? np : 0]);                                                   \
+            pn_point_tile<DT, C>(xb, N, n, has_trans, T, a1s, c1s, a2s, c2s, lane, h, Xf[np]);                    \
         }                                                                                                         \
     }
             DVQ_PN_TILE(0) DVQ_PN_TILE(1) DVQ_PN_TILE(2) DVQ_PN_TILE(3)
@@ -320,12 +264,7 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
                     for (int i = 0; i < 16; ++i) acc[np][i] = 0.f;
 #pragma unroll
                 for (int u = 0; u < Cfg::UPC; ++u) {
-                    if constexpr (DT == DVQ_BF16) {
-                        const bf16x8 w = *reinterpret_cast<const bf16x8*>(sb + (cc * Cfg::UPC + u) * 1024);
-#pragma unroll
-                        for (int np = 0; np < NV; ++np)
-                            acc[np] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xb[np][u], w, acc[np], 0, 0, 0);
-                    } else {
+                    {
                         const f32x4 w = *reinterpret_cast<const f32x4*>(sb + (cc * Cfg::UPC + u) * 1024);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -365,10 +304,253 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
     }
 }
 
+// ------------------------------------------------------------------ bf16, 16x16x32 tiles
+// The same fusion on the 16x16x32 MFMA (the shape that sustains the higher clock under a dense load).  A tile is 16
+// points; lane (c = lane & 15, q = lane >> 4) owns point c of its tile and the k-group q:
+//   conv1   the lane computes 16 of the 64 channels of its point: channels 32s + 8q + j (k-step s, j = 0..7), the
+//           B fragment of conv2;
+//   conv2   weights as A (rows = 16 output channels), points as B: the 16x16 accumulator has output channels
+//           16t + 4q + i of point c on lane (c, q);
+//   conv3   two such accumulators (t = 2ks, 2ks + 1), after ReLU and bf16 packing, are the A fragment of k-step ks
+//           (k order: 32ks + 4q + i, then 32ks + 16 + 4q + i -- the conv3 weights are packed in that order); weights
+//           as B (columns = 16 output channels): the result has output channel c on the lane and points 4q + i in
+//           the registers;
+//   max     over the registers of all point tiles, two lane exchanges across q, one LDS atomic per (wave, 16 channels).
+constexpr int kCt16 = kC3 / 16;      // 64 output-channel tiles of 16
+constexpr int kPnNP16 = 4;           // 16-point tiles per wave and chunk
+constexpr int kPnUPC16 = 4;          // 1-KiB conv3 weight units per channel tile (4 k-steps of 32)
+constexpr int kPnCPS16 = 4;          // channel tiles per LDS stage (16 KiB)
+
+// conv3 weights [1024,128] fp32 -> unit (ct, ks): lane (c, q) holds 8 bf16, j -> A3[16ct + c][32ks + 16(j>>2) + 4q + (j&3)]
+__global__ void pn_pack_w3_16_kernel(const float* __restrict__ a3, uint4* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= kCt16 * kPnUPC16 * 64) return;
+    const int l = t & 63, unit = t >> 6;
+    const int c = l & 15, q = l >> 4;
+    const int ct = unit / kPnUPC16, ks = unit % kPnUPC16;
+    const float* row = a3 + (ct * 16 + c) * kC2;
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16_bits(row[32 * ks + 16 * (j >> 2) + 4 * q + (j & 3)]);
+    uint4 v;
+    v.x = e[0] | (e[1] << 16); v.y = e[2] | (e[3] << 16); v.z = e[4] | (e[5] << 16); v.w = e[6] | (e[7] << 16);
+    out[t] = v;
+}
+
+// conv1 + conv2 for one tile of 16 points; leaves relu(conv2) as the four conv3 A fragments of the tile.
+template <int C>
+__device__ __forceinline__ void pn_point_tile16(const float* __restrict__ xb, int N, int n, bool has_trans, const float (&T)[9],
+                                                const float* a1s, const float* c1s, const char* a2s, const float* c2s,
+                                                int lane, int q, bf16x8 (&X)[4]) {
+    float p[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[c] = c < C ? xb[(int64_t)c * N + n] : 0.f;
+    if (has_trans) {  // xyz' = xyz * T  (pointnet_encoder.py:146)
+        const float q0 = p[0], q1 = p[1], q2 = p[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float v = q0 * T[j];
+            v = __builtin_fmaf(q1, T[3 + j], v);
+            v = __builtin_fmaf(q2, T[6 + j], v);
+            p[j] = v;
+        }
+    }
+    bf16x8 hb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int t4 = 0; t4 < 2; ++t4) {
+            const int ch0 = 32 * s + 8 * q + 4 * t4;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(c1s + ch0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(a1s + (ch0 + j) * 4);
+                float v = w[0] * p[0];
+                v = __builtin_fmaf(w[1], p[1], v);
+                v = __builtin_fmaf(w[2], p[2], v);
+                if (C > 3) v = __builtin_fmaf(w[3], p[3], v);
+                v += bias[j];
+                hb[s][4 * t4 + j] = static_cast<__bf16>(v > 0.f ? v : 0.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        f32x4 acc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = 2 * ks + u;
+            acc[u] = *reinterpret_cast<const f32x4*>(c2s + 16 * t + 4 * q);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(a2s + ((t * 2 + s) * 64 + lane) * 16);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hb[s], acc[u], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = acc[j >> 2][j & 3];
+            X[ks][j] = static_cast<__bf16>(v > 0.f ? v : 0.f);
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
+    const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb) {
+    constexpr int NP = kPnNP16;
+    constexpr int STAGE_BYTES = kPnCPS16 * kPnUPC16 * 1024;
+    constexpr int N_STAGES = kCt16 / kPnCPS16;
+    constexpr int A2_BYTES = 16 * 1024;
+    const int wpc = kPnWaves / cpb;                       // waves per cloud
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* w3s = smem;                                                         // [2][STAGE_BYTES]
+    char* a2s = smem + 2 * STAGE_BYTES;                                       // conv2 weights, fragment order
+    float* a1s = reinterpret_cast<float*>(a2s + A2_BYTES);                    // [64][4]
+    float* c1s = a1s + kC1 * 4;                                               // [64]
+    float* c2s = c1s + kC1;                                                   // [128]
+    float* bmax = c2s + kC2;                                                  // [cpb][1024] running max
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15;
+    const int q = lane >> 4;
+    const int cl = wave / wpc;                            // this wave's cloud within the block
+    const int lw = wave - cl * wpc;
+    int b = blockIdx.x * cpb + cl;
+    if (b >= B) b = B - 1;                                // a surplus slot recomputes the last cloud; its result is not stored
+    float* wmax = bmax + cl * kC3;
+
+    for (int i = tid; i < kC1 * 4; i += kPnThreads) {
+        const int ch = i >> 2, cc = i & 3;
+        a1s[i] = cc < C ? a1[ch * C + cc] : 0.f;
+    }
+    for (int i = tid; i < kC1; i += kPnThreads) c1s[i] = c1[i];
+    for (int i = tid; i < kC2; i += kPnThreads) c2s[i] = c2[i];
+    for (int i = tid; i < cpb * kC3; i += kPnThreads) bmax[i] = -__builtin_inff();
+    // conv2 weights A2 [128][64] -> unit (t, s): lane (cc, qq) holds A2[16t + cc][32s + 8qq .. +8]
+    for (int i = tid; i < 16 * 64; i += kPnThreads) {
+        const int l = i & 63, u = i >> 6;
+        const int cc = l & 15, qq = l >> 4;
+        const int t = u >> 1, s2 = u & 1;
+        const float* src = a2 + (16 * t + cc) * kC1 + 32 * s2 + 8 * qq;
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16_bits(src[j]);
+        uint4 v;
+        v.x = e[0] | (e[1] << 16); v.y = e[2] | (e[3] << 16); v.z = e[4] | (e[5] << 16); v.w = e[6] | (e[7] << 16);
+        *reinterpret_cast<uint4*>(a2s + i * 16) = v;
+    }
+    float T[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T[i] = trans ? trans[b * 9 + i] : ((i % 4) == 0 ? 1.f : 0.f);
+    const bool has_trans = trans != nullptr;
+    __syncthreads();
+
+    const float* xb = x + (int64_t)b * C * N;
+    const int pts_per_chunk = wpc * NP * 16;
+    const int n_chunks = (N + pts_per_chunk - 1) / pts_per_chunk;
+    const int n_tiles_cloud = (N + 15) / 16;
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        {
+            constexpr int UNITS = STAGE_BYTES / 1024;
+            for (int u = wave; u < UNITS; u += kPnWaves) glds16(w3p + (int64_t)u * 1024 + lane * 16, w3s + u * 1024);
+        }
+        // tiles are dealt to the waves round-robin, so the tiles past the end of the cloud fall into the higher slots
+        bf16x8 X[NP][4];
+        const int tile0 = chunk * (wpc * NP) + lw;
+        int nv = 0;
+#pragma unroll
+        for (int np = 0; np < NP; ++np) nv += (tile0 + np * wpc < n_tiles_cloud) ? 1 : 0;
+#define DVQ_PN_TILE16(np)                                                                              \
+    if (np < nv) {                                                                                     \
+        int n = (tile0 + np * wpc) * 16 + c;                                                           \
+        if (n >= N) n = N - 1; /* duplicate the last point: a duplicate cannot change a max */         \
+        pn_point_tile16<C>(xb, N, n, has_trans, T, a1s, c1s, a2s, c2s, lane, q, X[np]);                \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+        DVQ_PN_TILE16(0) DVQ_PN_TILE16(1) DVQ_PN_TILE16(2) DVQ_PN_TILE16(3)
+#undef DVQ_PN_TILE16
+        __syncthreads();  // stage 0 has landed
+
+#pragma unroll 1
+        for (int st = 0; st < N_STAGES; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < N_STAGES) {
+                constexpr int UNITS = STAGE_BYTES / 1024;
+                const char* src = w3p + (int64_t)(st + 1) * STAGE_BYTES;
+                char* dst = w3s + (buf ^ 1) * STAGE_BYTES;
+                for (int u = wave; u < UNITS; u += kPnWaves) glds16(src + (int64_t)u * 1024 + lane * 16, dst + u * 1024);
+            }
+            const char* sb = w3s + buf * STAGE_BYTES + lane * 16;
+            auto conv3_tile = [&](auto nvc, int cc) {
+                constexpr int NV = decltype(nvc)::value;
+                f32x4 acc[NV];
+#pragma unroll
+                for (int np = 0; np < NV; ++np) acc[np] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 w = *reinterpret_cast<const bf16x8*>(sb + (cc * kPnUPC16 + ks) * 1024);
+#pragma unroll
+                    for (int np = 0; np < NV; ++np) acc[np] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[np][ks], w, acc[np], 0, 0, 0);
+                }
+                float m = acc[0][0];
+#pragma unroll
+                for (int np = 0; np < NV; ++np)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) m = fmaxf(m, acc[np][i]);
+                // all 64 lanes fold into the block's running maximum: the four lanes of a channel (one per k-group, each
+                // with its own four points of every tile) meet in the LDS atomic unit, which costs less than two lane
+                // exchanges and the wait for them
+                __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float*)(wmax + (st * kPnCPS16 + cc) * 16 + c), m, 0, 0, false);
+            };
+            if (nv == 4) {
+#pragma unroll
+                for (int cc = 0; cc < kPnCPS16; ++cc) conv3_tile(std::integral_constant<int, 4>{}, cc);
+            } else if (nv == 3) {
+#pragma unroll 1
+                for (int cc = 0; cc < kPnCPS16; ++cc) conv3_tile(std::integral_constant<int, 3>{}, cc);
+            } else if (nv == 2) {
+#pragma unroll 1
+                for (int cc = 0; cc < kPnCPS16; ++cc) conv3_tile(std::integral_constant<int, 2>{}, cc);
+            } else if (nv == 1) {
+#pragma unroll 1
+                for (int cc = 0; cc < kPnCPS16; ++cc) conv3_tile(std::integral_constant<int, 1>{}, cc);
+            }
+            __syncthreads();
+        }
+    }
+
+    for (int i = tid; i < cpb * kC3; i += kPnThreads) {
+        const int cloud = blockIdx.x * cpb + i / kC3, ch = i % kC3;
+        if (cloud >= B) break;
+        float v = bmax[i] + c3[ch];
+        if (relu3) v = v > 0.f ? v : 0.f;
+        feat[(int64_t)cloud * kC3 + ch] = v;
+    }
+}
+
 template <int DT>
 static size_t pn_lds_bytes(int cpb) {
     typedef PnCfg<DT> Cfg;
     return 2 * (size_t)Cfg::CPS * Cfg::UPC * 1024 + (size_t)Cfg::A2_UNITS * 1024 + (kC1 * 4 + kC1 + kC2) * 4 + (size_t)cpb * kC3 * 4;
+}
+
+template <int C>
+static int pn_launch16(const float* x, const float* trans, int B, int N, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
+    auto kern = pointnet_mlp_max_bf16_kernel<C>;
+    int cpb = 1;
+    while (cpb < 4 && N <= (kPnWaves / (2 * cpb)) * kPnNP16 * 16) cpb *= 2;
+    const size_t lds = 2 * (size_t)kPnCPS16 * kPnUPC16 * 1024 + 16 * 1024 + (kC1 * 4 + kC1 + kC2) * 4 + (size_t)cpb * kC3 * 4;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "pointnet_mlp_max")) return rc;
+    hipLaunchKernelGGL(kern, dim3((B + cpb - 1) / cpb), dim3(kPnThreads), lds, st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
+                       reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat, B, cpb);
+    return check_launch("pointnet_mlp_max");
 }
 
 template <int DT, int C>
@@ -400,9 +582,8 @@ extern "C" int dvq_pointnet_pack_w3(const float* a3, int dtype, void* w3p, void*
     if (!a3 || !w3p) return fail(DVQ_EINVAL, "pointnet_pack_w3: null pointer");
     if (((uintptr_t)a3 & 15) || ((uintptr_t)w3p & 15)) return fail(DVQ_EINVAL, "pointnet_pack_w3: pointers must be 16-byte aligned");
     if (dtype == DVQ_BF16) {
-        const int total = kCt * PnCfg<DVQ_BF16>::UPC * 64;
-        hipLaunchKernelGGL((pn_pack_w3_kernel<DVQ_BF16>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), a3,
-                           reinterpret_cast<uint4*>(w3p));
+        const int total = kCt16 * kPnUPC16 * 64;
+        hipLaunchKernelGGL(pn_pack_w3_16_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), a3, reinterpret_cast<uint4*>(w3p));
     } else if (dtype == DVQ_F32) {
         const int total = kCt * PnCfg<DVQ_F32>::UPC * 64;
         hipLaunchKernelGGL((pn_pack_w3_kernel<DVQ_F32>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), a3,
@@ -423,8 +604,7 @@ extern "C" int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, i
     if (((uintptr_t)w->a2 & 15) || ((uintptr_t)w->w3p & 15)) return fail(DVQ_EINVAL, "pointnet: a2 and w3p must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     if (dtype == DVQ_BF16) {
-        return C == 3 ? pn_launch<DVQ_BF16, 3>(x, trans, B, N, w, relu3, feat_out, st)
-                      : pn_launch<DVQ_BF16, 4>(x, trans, B, N, w, relu3, feat_out, st);
+        return C == 3 ? pn_launch16<3>(x, trans, B, N, w, relu3, feat_out, st) : pn_launch16<4>(x, trans, B, N, w, relu3, feat_out, st);
     } else if (dtype == DVQ_F32) {
         return C == 3 ? pn_launch<DVQ_F32, 3>(x, trans, B, N, w, relu3, feat_out, st)
                       : pn_launch<DVQ_F32, 4>(x, trans, B, N, w, relu3, feat_out, st);

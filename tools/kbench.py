@@ -29,7 +29,7 @@ def timeit(fn, iters=10, warm=2):
 def pointnet():
     from network.pointnet_encoder import PointNetEncoder
     sd = synth.gennet_state_dict(0, with_prior=False)
-    for C, N, B in ((4, 3000, 4096), (3, 778, 4096), (3, 212, 4096), (3, 123, 4096), (3, 83, 4096), (4, 3000, 64), (4, 3000, 1)):
+    for C, N, B in [tuple(int(v) for v in os.environ["DVQ_PN_CASES"].split(","))] if os.environ.get("DVQ_PN_CASES") else ((4, 3000, 4096), (3, 778, 4096), (3, 212, 4096), (3, 123, 4096), (3, 83, 4096), (4, 3000, 64), (4, 3000, 1)):
         enc = PointNetEncoder(channel=C)
         pre = "obj_encoder_type." if C == 4 else "recon_encoder."
         enc.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
