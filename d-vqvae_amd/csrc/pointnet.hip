@@ -488,40 +488,41 @@ __global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_kernel(
                 for (int u = wave; u < UNITS; u += kPnWaves) glds16(src + (int64_t)u * 1024 + lane * 16, dst + u * 1024);
             }
             const char* sb = w3s + buf * STAGE_BYTES + lane * 16;
-            auto conv3_tile = [&](auto nvc, int cc) {
+            // conv3 of the stage's four channel tiles for the first NV point tiles of this wave.  The four maxima go to
+            // LDS together after the last tile: an LDS atomic between the tiles would pin the order of the weight
+            // reads around it (and the compiler drains the in-flight weight copies before each one).
+            auto conv3_stage = [&](auto nvc) {
                 constexpr int NV = decltype(nvc)::value;
-                f32x4 acc[NV];
+                float m[kPnCPS16];
 #pragma unroll
-                for (int np = 0; np < NV; ++np) acc[np] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int cc = 0; cc < kPnCPS16; ++cc) {
+                    f32x4 acc[NV];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 w = *reinterpret_cast<const bf16x8*>(sb + (cc * kPnUPC16 + ks) * 1024);
+                    for (int np = 0; np < NV; ++np) acc[np] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int np = 0; np < NV; ++np) acc[np] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[np][ks], w, acc[np], 0, 0, 0);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const bf16x8 w = *reinterpret_cast<const bf16x8*>(sb + (cc * kPnUPC16 + ks) * 1024);
+#pragma unroll
+                        for (int np = 0; np < NV; ++np) acc[np] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[np][ks], w, acc[np], 0, 0, 0);
+                    }
+                    float mm = acc[0][0];
+#pragma unroll
+                    for (int np = 0; np < NV; ++np)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) mm = fmaxf(mm, acc[np][i]);
+                    m[cc] = mm;
                 }
-                float m = acc[0][0];
-#pragma unroll
-                for (int np = 0; np < NV; ++np)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) m = fmaxf(m, acc[np][i]);
                 // all 64 lanes fold into the block's running maximum: the four lanes of a channel (one per k-group, each
                 // with its own four points of every tile) meet in the LDS atomic unit, which costs less than two lane
                 // exchanges and the wait for them
-                __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float*)(wmax + (st * kPnCPS16 + cc) * 16 + c), m, 0, 0, false);
-            };
-            if (nv == 4) {
 #pragma unroll
-                for (int cc = 0; cc < kPnCPS16; ++cc) conv3_tile(std::integral_constant<int, 4>{}, cc);
-            } else if (nv == 3) {
-#pragma unroll 1
-                for (int cc = 0; cc < kPnCPS16; ++cc) conv3_tile(std::integral_constant<int, 3>{}, cc);
-            } else if (nv == 2) {
-#pragma unroll 1
-                for (int cc = 0; cc < kPnCPS16; ++cc) conv3_tile(std::integral_constant<int, 2>{}, cc);
-            } else if (nv == 1) {
-#pragma unroll 1
-                for (int cc = 0; cc < kPnCPS16; ++cc) conv3_tile(std::integral_constant<int, 1>{}, cc);
-            }
+                for (int cc = 0; cc < kPnCPS16; ++cc)
+                    __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float*)(wmax + (st * kPnCPS16 + cc) * 16 + c), m[cc], 0, 0, false);
+            };
+            if (nv == 4) conv3_stage(std::integral_constant<int, 4>{});
+            else if (nv == 3) conv3_stage(std::integral_constant<int, 3>{});
+            else if (nv == 2) conv3_stage(std::integral_constant<int, 2>{});
+            else if (nv == 1) conv3_stage(std::integral_constant<int, 1>{});
             __syncthreads();
         }
     }

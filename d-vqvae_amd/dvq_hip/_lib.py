@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdvq_hip.so")
+LIB_PATH = os.environ.get("DVQ_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdvq_hip.so")
 
 DVQ_F32 = 0
 DVQ_BF16 = 1
