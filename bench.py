@@ -230,12 +230,12 @@ def main():
             ach = flops / avg_ms / 1e9
             # HBM bytes per launch from the FETCH_SIZE (x2, the gfx950 correction for 16-B-per-lane streams) and
             # WRITE_SIZE counters, collected in separate rocprofv3 --pmc passes of this workload
-            # (profiles/r1c_pmc_fetch_write.txt); only valid for the configuration it was measured on
+            # (profiles/r1g_pmc_fetch_write.txt); only valid for the configuration it was measured on
             traffic = 2.173e8 if (kb, kc, kn, args.dtype) == (4096, 4, 3000, "bf16") else None
             result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1),
                                   "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                   "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
-                                  "traffic_note": "HBM bytes per launch, PMC passes in profiles/r1c_pmc_fetch_write.txt; "
+                                  "traffic_note": "HBM bytes per launch, PMC passes in profiles/r1g_pmc_fetch_write.txt; "
                                                   "algorithmic bytes 2.134e8",
                                   "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
                                   # half of the launches share the GPU with the prior running on the other stream; the
