@@ -8,7 +8,8 @@ import torch
 
 def set_compute_dtype(model, dtype):
     """Select exact-fp32 (torch.float32) or bf16-operand (torch.bfloat16) matrix-core
-    arithmetic for every PointNet encoder inside `model`."""
+    arithmetic for every PointNet encoder and MLP head inside `model` (the heads switch to bf16 operands only for
+    batches of at least ops.LINEAR_BF16_MIN_ROWS rows; smaller batches stay in fp32)."""
     if dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("dtype must be torch.float32 or torch.bfloat16")
     for m in model.modules():

@@ -63,6 +63,8 @@ SIGNATURES = {
     "dvq_pointnet_mlp_max": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DvqPointMlp), c_int, c_int, c_void_p, c_void_p]),
     "dvq_fold_bn": (c_int, [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dvq_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "dvq_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "dvq_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "dvq_prior_packed_bytes": (c_size_t, [c_int, c_int]),
     "dvq_prior_pack_weight": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

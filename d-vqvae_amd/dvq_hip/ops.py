@@ -169,10 +169,28 @@ def pointnet_mlp_max(x: torch.Tensor, trans: Optional[torch.Tensor], w: dict, re
 
 
 # ----------------------------------------------------------------------- linear
+# below this many rows the fp32 kernels are bound by latency, not by the matrix cores, and bf16 operands buy nothing
+LINEAR_BF16_MIN_ROWS = 512
+
+
+def to_bf16(w: torch.Tensor) -> torch.Tensor:
+    """bf16 copy (round to nearest even) of a contiguous fp32 tensor, as dvq_linear_bf16 wants its weight."""
+    _need_gpu(w)
+    w = w.contiguous()
+    out = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().dvq_to_bf16(_p(w), _p(out), w.numel(), _stream(w))
+    _lib.check(rc, "dvq_to_bf16")
+    return out
+
+
 def linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
-           add_identity3: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x W^T + b) in fp32.  x [M,K] and `out` [M,N] may be column slices of wider
-    row-major buffers (unit inner stride)."""
+           add_identity3: bool = False, out: Optional[torch.Tensor] = None,
+           W_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x W^T + b).  x [M,K] and `out` [M,N] may be column slices of wider row-major buffers
+    (unit inner stride).  fp32 arithmetic, unless a bf16 copy of the weight is passed as well and the
+    shape is one the bf16 kernel takes (M >= LINEAR_BF16_MIN_ROWS, K % 32 == 0, N >= 64): then x is
+    rounded to bf16 on the fly and the products accumulate in fp32."""
     _need_gpu(W, b)
     if not x.is_cuda or x.stride(-1) != 1 or x.dim() != 2:
         raise RuntimeError("linear: x must be a 2-D HIP tensor with unit inner stride")
@@ -184,6 +202,13 @@ def linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], relu: bo
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     ldx = x.stride(0) if M > 1 else max(K, x.stride(0))
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
+    if W_bf16 is not None and not add_identity3 and M >= LINEAR_BF16_MIN_ROWS and K % 32 == 0 and N >= 64:
+        if W_bf16.dtype != torch.bfloat16 or tuple(W_bf16.shape) != (N, K) or not W_bf16.is_contiguous():
+            raise RuntimeError("linear: W_bf16 must be a contiguous bf16 copy of W")
+        with torch.cuda.device(x.device):
+            rc = _lib.load().dvq_linear_bf16(_p(x), ldx, _p(W_bf16), _p(b), M, K, N, int(relu), _p(out), ldy, _stream(x))
+        _lib.check(rc, "dvq_linear_bf16")
+        return out
     with torch.cuda.device(x.device):
         rc = _lib.load().dvq_linear(_p(x), ldx, _p(W), _p(b), M, K, N, int(relu), int(add_identity3), _p(out), ldy, _stream(x))
     _lib.check(rc, "dvq_linear")

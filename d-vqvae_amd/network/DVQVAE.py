@@ -18,8 +18,18 @@ from network.pointnet_encoder import PointNetEncoder
 from network.VQVAE import VQVAE
 
 
-def _linear(layer, x, relu=False, out=None):
-    return ops.linear(x, layer.weight.detach(), layer.bias.detach(), relu=relu, out=out)
+def _linear(layer, x, relu=False, out=None, bf16=False):
+    """nn.Linear (+ReLU) on the HIP kernels; with bf16=True a bf16 copy of the weight (kept on the layer, refreshed
+    when the weight changes) lets large batches run on the bf16 matrix-core kernel."""
+    W = layer.weight.detach()
+    Wb = None
+    if bf16 and W.is_cuda and x.shape[0] >= ops.LINEAR_BF16_MIN_ROWS:
+        key = (W.data_ptr(), W._version)
+        if getattr(layer, "_dvq_bf16_key", None) != key:
+            layer._dvq_bf16 = ops.to_bf16(W)
+            layer._dvq_bf16_key = key
+        Wb = layer._dvq_bf16
+    return ops.linear(x, W, layer.bias.detach(), relu=relu, out=out, W_bf16=Wb)
 
 
 class Encoder(nn.Module):
@@ -31,13 +41,15 @@ class Encoder(nn.Module):
             self.MLP.add_module(name="A{:d}".format(i), module=nn.ReLU())
         self.linear_means = nn.Linear(layer_sizes[-1], latent_size)
         self.linear_log_var = nn.Linear(layer_sizes[-1], latent_size)  # in the checkpoint, never used
+        self.compute_dtype = torch.float32
 
     def forward(self, x, out=None):
         x = x.detach()
+        bf16 = self.compute_dtype == torch.bfloat16
         for m in self.MLP:
             if isinstance(m, nn.Linear):
-                x = _linear(m, x, relu=True)
-        return _linear(self.linear_means, x, out=out)
+                x = _linear(m, x, relu=True, bf16=bf16)
+        return _linear(self.linear_means, x, out=out, bf16=bf16)
 
 
 class Decoder(nn.Module):
@@ -48,12 +60,14 @@ class Decoder(nn.Module):
             self.MLP.add_module(name="L{:d}".format(i), module=nn.Linear(in_size, out_size))
             if i + 1 < len(layer_sizes):
                 self.MLP.add_module(name="A{:d}".format(i), module=nn.ReLU())
+        self.compute_dtype = torch.float32
 
     def forward(self, z):
         x = z.detach()
         layers = [m for m in self.MLP if isinstance(m, nn.Linear)]
+        bf16 = self.compute_dtype == torch.bfloat16
         for i, m in enumerate(layers):
-            x = _linear(m, x, relu=(i + 1 < len(layers)))
+            x = _linear(m, x, relu=(i + 1 < len(layers)), bf16=bf16)
         return x
 
 

@@ -86,17 +86,22 @@ class STN3d(nn.Module):
             trunk = _Trunk(self, _dtype_code(self.compute_dtype))
             f1 = _fold(self.fc1, self.bn4)
             f2 = _fold(self.fc2, self.bn5)
+            if self.compute_dtype == torch.bfloat16:   # bf16 copies of the folded weights for the large-batch kernel
+                f1 = f1 + (ops.to_bf16(f1[0]),)
+                f2 = f2 + (ops.to_bf16(f2[0]),)
+            else:
+                f1, f2 = f1 + (None,), f2 + (None,)
             self._cache = (trunk, f1, f2)
             self._cache_key = key
         return self._cache
 
     def forward(self, x):
         x = _check_input(self, x, self.channel)
-        trunk, (w4, b4), (w5, b5) = self._packed()
+        trunk, (w4, b4, w4h), (w5, b5, w5h) = self._packed()
         # conv/bn/relu x3 + max over points (pointnet_encoder.py:29-33)
         g = ops.pointnet_mlp_max(x, None, trunk.as_dict(), True, _dtype_code(self.compute_dtype))
-        g = ops.linear(g, w4, b4, relu=True)                      # fc1+bn4+relu (:35)
-        g = ops.linear(g, w5, b5, relu=True)                      # fc2+bn5+relu (:36)
+        g = ops.linear(g, w4, b4, relu=True, W_bf16=w4h)          # fc1+bn4+relu (:35)
+        g = ops.linear(g, w5, b5, relu=True, W_bf16=w5h)          # fc2+bn5+relu (:36)
         g = ops.linear(g, self.fc3.weight.detach(), self.fc3.bias.detach(), add_identity3=True)  # fc3 + I (:37-43)
         return g.view(-1, 3, 3)
 

@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 103   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 104   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -96,6 +96,14 @@ size_t dvq_pointnet_w3_bytes(int dtype);
 int dvq_pointnet_pack_w3(const float* a3 /* [1024,128] */, int dtype, void* w3p, void* stream);
 int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, int C, int N,
                          const DvqPointMlp* w, int relu3, int dtype, float* feat_out, void* stream);
+
+/* The same product with bf16 matrix-core operands and fp32 accumulation (the throughput configuration of the
+ * heads: DVQ-VAE/network/DVQVAE.py:161-185, pointnet_encoder.py:35-36): x fp32 [M,K] (row stride ldx) is rounded to
+ * bf16 as it is read, Wb is the weight as bf16 [N,K] row-major (dvq_to_bf16 makes it), y = act(x Wb^T + b) fp32.
+ * K % 32 == 0. */
+int dvq_to_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
+int dvq_linear_bf16(const float* x, int64_t ldx, const void* Wb, const float* b, int M, int K, int N,
+                    int relu, float* y, int64_t ldy, void* stream);
 
 /* Folds an eval-mode BatchNorm1d into the preceding affine layer:
  *   s = gamma / sqrt(var + eps);  A = s * W (row-wise);  c = s * (b - mean) + beta.

@@ -76,6 +76,30 @@ def test_linear_vs_torch(M, K, N, relu):
         assert (y2.cpu().double() - (ref + eye)).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("M,K,N,relu", [(4096, 2560, 1024, True), (600, 1024, 512, True), (513, 64, 64, False),
+                                        (1000, 2048, 200, False)])
+def test_linear_bf16_operands_vs_fp64_on_rounded_inputs(M, K, N, relu):
+    """The bf16 head kernel: operands rounded to bf16 (x on the fly, W beforehand), products exact in fp32,
+    fp32 accumulation.  The fp64 product of the ROUNDED operands is the reference; what is left is the order of the
+    fp32 accumulation.  Ragged M and N (partial tiles), a strided input and a strided output are covered; batches
+    below ops.LINEAR_BF16_MIN_ROWS must take the fp32 kernel even when the bf16 weight is offered."""
+    r = np.random.default_rng(M + K)
+    x = torch.from_numpy(r.normal(0, 1, (M, K + 8)).astype(np.float32)).to(DEV)[:, 4:4 + K]
+    W = torch.from_numpy(r.normal(0, K ** -0.5, (N, K)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(r.normal(0, 0.1, (N,)).astype(np.float32)).to(DEV)
+    Wb = ops.to_bf16(W)
+    assert torch.equal(Wb, W.to(torch.bfloat16))
+    wide = torch.zeros(M, N + 16, device=DEV)
+    y = ops.linear(x, W, b, relu=relu, out=wide[:, 8:8 + N], W_bf16=Wb)
+    ref = torch.nn.functional.linear(x.to(torch.bfloat16).double(), Wb.double(), b.double())
+    if relu:
+        ref = ref.relu()
+    assert (y.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert wide[:, :8].abs().sum() == 0 and wide[:, 8 + N:].abs().sum() == 0
+    small = ops.linear(x[:100], W, b, relu=relu, W_bf16=Wb)
+    assert torch.equal(small, ops.linear(x[:100], W, b, relu=relu))
+
+
 def test_mlp_heads_vs_reference_golden():
     from network.DVQVAE import Decoder, Encoder
     g = load_golden("mlp")

@@ -92,6 +92,10 @@ def linear():
         b = torch.randn(N, device=dev)
         ms = timeit(lambda: ops.linear(x, W, b, relu=True))
         print(f"linear M={M_} K={K} N={N}: {ms:.4f} ms  {2.0 * M_ * K * N / ms / 1e9:.1f} TFLOP/s", flush=True)
+        if M_ >= ops.LINEAR_BF16_MIN_ROWS:
+            Wb = ops.to_bf16(W)
+            ms = timeit(lambda: ops.linear(x, W, b, relu=True, W_bf16=Wb))
+            print(f"linear M={M_} K={K} N={N} bf16 operands: {ms:.4f} ms  {2.0 * M_ * K * N / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
 def prior():
