@@ -17,6 +17,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 constexpr int kNumCU = 256;
+constexpr int kNumXCD = 8;
+
+// Workgroups are dealt to the 8 XCDs round-robin in the order of their linear id, and every XCD has an L2 of its own.
+// For a grid of nx (fast) x ny tiles whose workgroups share one operand along x and another along y, the plain
+// mapping gives XCD k the column tx = k (mod 8) of EVERY row: its L2 then has to fetch the whole row operand.
+// This mapping gives XCD k the rows ty = k (mod 8) and every column instead: 1/8 of the row operand plus the
+// column operand.  `lin` is the workgroup's linear id; returns false (plain mapping) when ny is not a multiple of 8.
+__device__ __forceinline__ bool xcd_tile(int lin, int nx, int ny, int& tx, int& ty) {
+    if ((ny % kNumXCD) != 0) { tx = lin % nx; ty = lin / nx; return false; }
+    const int xcd = lin % kNumXCD, i = lin / kNumXCD;
+    tx = i % nx;
+    ty = (i / nx) * kNumXCD + xcd;
+    return true;
+}
 
 // Per-thread error text returned by dvq_last_error().
 void set_error(const char* fmt, ...);

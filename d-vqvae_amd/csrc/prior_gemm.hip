@@ -104,17 +104,20 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
     const int SB = (M + 31) / 32;
     const int n_ob = N / 32;
 
+    // column tile bx (weights shared along it), row tile by (activations shared along it), dealt XCD-aware
+    int bx, by;
+    xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
     int ob[NO];
     if (EPI == PG_GATE) {
         const int half = n_ob / 2;
 #pragma unroll
-        for (int t = 0; t < NO / 2; ++t) { ob[t] = (NO / 2) * blockIdx.x + t; ob[t + NO / 2] = half + (NO / 2) * blockIdx.x + t; }
+        for (int t = 0; t < NO / 2; ++t) { ob[t] = (NO / 2) * bx + t; ob[t + NO / 2] = half + (NO / 2) * bx + t; }
     } else {
 #pragma unroll
-        for (int t = 0; t < NO; ++t) ob[t] = NO * blockIdx.x + t;
+        for (int t = 0; t < NO; ++t) ob[t] = NO * bx + t;
     }
     int sb[NS];
-    sb[0] = blockIdx.y * kPgWaves + wave;
+    sb[0] = by * kPgWaves + wave;
     const bool live0 = sb[0] < SB;
     const bool live1 = false;
     if (sb[0] >= SB) sb[0] = SB - 1;   // a surplus tile recomputes the last one; its stores are skipped
@@ -333,10 +336,12 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int
     const int c = lane & 31, h = lane >> 5;
     const int SB = (M + 31) / 32;
     const int n_ob = N / 32, half = n_ob / 2;
+    int bx, by;
+    xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
     int ob[NO];
 #pragma unroll
-    for (int t = 0; t < NO / 2; ++t) { ob[t] = (NO / 2) * blockIdx.x + t; ob[t + NO / 2] = half + (NO / 2) * blockIdx.x + t; }
-    int sb = blockIdx.y * kPgWaves + wave;
+    for (int t = 0; t < NO / 2; ++t) { ob[t] = (NO / 2) * bx + t; ob[t + NO / 2] = half + (NO / 2) * bx + t; }
+    int sb = by * kPgWaves + wave;
     const bool live = sb < SB;
     if (!live) sb = SB - 1;
     const int KB = d.kb;
