@@ -31,9 +31,13 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X
 FLOP_PER_POINT = {3: 2 * (3 * 64 + 64 * 128 + 128 * 1024), 4: 2 * (4 * 64 + 64 * 128 + 128 * 1024)}
 
 
-def timed_steps(fn, steps, warmup, device, barrier, kernel_timers=False):
+def timed_steps(fn, steps, warmup, device, barrier, kernel_timers=False, finish=None):
+    """`finish` completes whatever the last call of `fn` left running (an all-gather in flight); it is
+    inside the timed region, so every step's result is complete when the clock stops."""
     for _ in range(warmup):
         fn()
+    if finish:
+        finish()
     barrier()
     torch.cuda.synchronize(device)
     if kernel_timers:
@@ -41,6 +45,8 @@ def timed_steps(fn, steps, warmup, device, barrier, kernel_timers=False):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    if finish:
+        finish()
     barrier()
     torch.cuda.synchronize(device)
     return time.perf_counter() - t0
@@ -185,10 +191,21 @@ def main():
         from dvq_hip.tta import GraspRefiner
         refiner = GraspRefiner(gen.rh_mano, iters=args.tta_iters)
 
+    # The all-gather of a step's vertices runs beside the next step's kernels: one step's collective is in
+    # flight at a time, and finish_gathers() completes the last one before the clock stops.
+    in_flight = []
+
+    def finish_gathers():
+        for w in in_flight:
+            w.wait()
+        in_flight.clear()
+
     def step(prior=args.prior):
         if refiner is None:
             out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None,
-                               gather=world > 1, n_total=world * B)
+                               gather=world > 1, n_total=world * B, async_gather=True)
+            finish_gathers()                       # the previous step's
+            in_flight.extend(out.get("pending", []))
             return out["vertices"]
         # generation, then the adaptation loop on this rank's grasps, then the final hand and the gather
         out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None)
@@ -200,7 +217,7 @@ def main():
             verts = parallel.gather_rows(verts, world * B)
         return verts
 
-    elapsed = timed_steps(step, args.steps, args.warmup, device, barrier, kernel_timers=True)
+    elapsed = timed_steps(step, args.steps, args.warmup, device, barrier, kernel_timers=True, finish=finish_gathers)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

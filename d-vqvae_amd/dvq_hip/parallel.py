@@ -26,16 +26,21 @@ def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     return b, min(n, b + per)
 
 
-def gather_rows(t: torch.Tensor, n_total: int = None) -> torch.Tensor:
+def gather_rows(t: torch.Tensor, n_total: int = None, async_op: bool = False):
     """All-gather equally sized per-rank row blocks [m, ...] into [world*m, ...] (out of place);
-    `n_total` trims padding rows when the last shard was short."""
+    `n_total` trims padding rows when the last shard was short.
+    With async_op=True returns (rows, work): the collective runs on the backend's own stream beside
+    whatever is launched next, and `rows` is complete once work.wait() has been called (work is None
+    when there is nothing to exchange)."""
     rank, ws = world()
     if ws == 1:
-        return t if n_total is None else t[:n_total]
+        out = t if n_total is None else t[:n_total]
+        return (out, None) if async_op else out
     t = t.contiguous()
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t)
-    return out if n_total is None else out[:n_total]
+    work = dist.all_gather_into_tensor(out, t, async_op=async_op)
+    out = out if n_total is None else out[:n_total]
+    return (out, work) if async_op else out
 
 
 def pad_rows(t: torch.Tensor, m: int) -> torch.Tensor:

@@ -48,10 +48,12 @@ class GraspGenerator:
 
     @torch.no_grad()
     def generate(self, obj: torch.Tensor, first_id: int = 0, x_tilde: Optional[torch.Tensor] = None,
-                 gather: bool = False, n_total: Optional[int] = None):
+                 gather: bool = False, n_total: Optional[int] = None, async_gather: bool = False):
         """obj [B,4,N] (this rank's shard; object b has global id first_id+b).
         Returns dict(recon_param [B,61], vertices [B,778,3]); with gather=True the vertices
-        (and parameters) of all ranks, in global object order."""
+        (and parameters) of all ranks, in global object order.  With async_gather=True the two
+        all-gathers are left running beside whatever the caller launches next: the dict then carries
+        "pending", the work handles to wait() on before the gathered tensors are read."""
         B = obj.shape[0]
         if x_tilde is None:
             ids = torch.arange(first_id, first_id + B, device=obj.device)
@@ -63,6 +65,10 @@ class GraspGenerator:
         out = self.rh_mano(betas=param[:, :10], global_orient=param[:, 10:13].contiguous(),
                            hand_pose=param[:, 13:58].contiguous(), transl=param[:, 58:].contiguous())
         verts = out.vertices
+        if gather and async_gather:
+            verts, wv = parallel.gather_rows(verts, n_total, async_op=True)
+            param, wp = parallel.gather_rows(param, n_total, async_op=True)
+            return dict(recon_param=param, vertices=verts, pending=[w for w in (wv, wp) if w is not None])
         if gather:
             verts = parallel.gather_rows(verts, n_total)
             param = parallel.gather_rows(param, n_total)

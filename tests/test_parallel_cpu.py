@@ -51,6 +51,13 @@ def _worker(rank, world, port, n, q):
     # stand-in for the per-object computation: anything that is a function of the object alone
     verts = torch.stack([objs.sum(dim=(1, 2)), u.sum(dim=1).float()], 1).unsqueeze(-1).expand(-1, -1, 3).contiguous()
     out = parallel.gather_rows(parallel.pad_rows(verts, per), n_total=n)
+    # the asynchronous form (the bench keeps one step's gather in flight beside the next step): two collectives
+    # outstanding at once, complete after their wait()
+    out_a, wa = parallel.gather_rows(parallel.pad_rows(verts, per), n_total=n, async_op=True)
+    out_b, wb = parallel.gather_rows(parallel.pad_rows(verts * 2, per), n_total=n, async_op=True)
+    wa.wait()
+    wb.wait()
+    assert torch.equal(out_a, out) and torch.equal(out_b, out * 2)
     if rank == 0:
         q.put(out.numpy())
     dist.barrier()
