@@ -65,11 +65,12 @@ def kernel_stats(name_prefix):
     return best
 
 
-def vq_microbench(device, n=1 << 20, iters=5):
-    """Isolated nearest-codebook search: 1 Mi latents, reference codebook shapes + K sweep."""
+def vq_microbench(device, n_rows=1 << 20, iters=5):
+    """Isolated nearest-codebook search: 1 Mi latents, reference codebook shapes (128 x 256 and 128 x 1024) + K sweep."""
     out = []
     for dtype, name in ((torch.bfloat16, "bf16"), (torch.float32, "fp32")):
-        for K, D in ((128, 256), (512, 256), (2048, 256), (8192, 256)):
+        for K, D in ((128, 256), (512, 256), (2048, 256), (8192, 256), (128, 1024)):
+            n = n_rows if D == 256 else n_rows // 4     # the 1024-wide object codebook: same bytes of latents
             g = torch.Generator(device).manual_seed(K)
             E = torch.randn(K, D, device=device, generator=g)
             j = torch.randint(0, K, (n,), device=device, generator=g)
