@@ -178,3 +178,24 @@ def test_mano_file_reader_builds_arrays_and_refuses_code(tmp_path):
     import mano
     m = mano.load(str(path), use_pca=True, num_pca_comps=45, batch_size=1, flat_hand_mean=True)
     assert m.is_rhand and m.v_template.shape == (778, 3)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The newest bench line kept under profiles/ carries every field the measurement contract names."""
+    import glob
+    import json
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    assert paths, "no bench line under profiles/"
+    line = open(paths[-1]).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "grasps generated/sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - d["n_gpus"] * d["config"]["objects_per_gpu"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-3 * d["value"]
