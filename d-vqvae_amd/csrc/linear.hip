@@ -18,13 +18,25 @@ namespace dvq {
 
 constexpr int kLinWaves = 4;
 
+// Operands of up to kLinMaxBatch products of one shape folded into one grid (blockIdx.y picks the product).
+constexpr int kLinMaxBatch = 8;
+struct LinBatch {
+    const float* x[kLinMaxBatch];
+    const void* W[kLinMaxBatch];
+    const float* b[kLinMaxBatch];
+    float* y[kLinMaxBatch];
+};
+
 // RM x RN tiles of 32x32 per wave: every x fragment loaded feeds RN MFMA chains and every W fragment RM, so the
 // L1/L2 traffic per FLOP falls by 2 RM RN / (RM + RN).  Each output element is the same k-ordered fmaf chain
 // whatever the tiling, so the result does not depend on RM, RN.
 template <int RM, int RN>
 __global__ __launch_bounds__(kLinWaves * 64) void linear_kernel(
-    const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, const float* __restrict__ bias, int M, int K,
-    int N, int relu, int add_id3, float* __restrict__ y, int64_t ldy) {
+    LinBatch p, int64_t ldx, int M, int K, int N, int relu, int add_id3, int64_t ldy) {
+    const float* __restrict__ x = p.x[blockIdx.y];
+    const float* __restrict__ W = reinterpret_cast<const float*>(p.W[blockIdx.y]);
+    const float* __restrict__ bias = p.b[blockIdx.y];
+    float* __restrict__ y = p.y[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 31;
@@ -107,8 +119,11 @@ __global__ __launch_bounds__(kLinWaves * 64) void linear_kernel(
 constexpr int kSkinnyM = 16;
 template <int MR>
 __global__ __launch_bounds__(256) void linear_skinny_kernel(
-    const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, const float* __restrict__ bias, int M, int K,
-    int N, int relu, int add_id3, float* __restrict__ y, int64_t ldy) {
+    LinBatch p, int64_t ldx, int M, int K, int N, int relu, int add_id3, int64_t ldy) {
+    const float* __restrict__ x = p.x[blockIdx.y];
+    const float* __restrict__ W = reinterpret_cast<const float*>(p.W[blockIdx.y]);
+    const float* __restrict__ bias = p.b[blockIdx.y];
+    float* __restrict__ y = p.y[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= N) return;
@@ -156,8 +171,11 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
 // the MFMAs of the current one.
 template <int RM, int RN>
 __global__ __launch_bounds__(256) void linear_bf16_kernel(
-    const float* __restrict__ x, int64_t ldx, const unsigned short* __restrict__ Wb, const float* __restrict__ bias, int M,
-    int K, int N, int relu, float* __restrict__ y, int64_t ldy) {
+    LinBatch p, int64_t ldx, int M, int K, int N, int relu, int64_t ldy) {
+    const float* __restrict__ x = p.x[blockIdx.y];
+    const unsigned short* __restrict__ Wb = reinterpret_cast<const unsigned short*>(p.W[blockIdx.y]);
+    const float* __restrict__ bias = p.b[blockIdx.y];
+    float* __restrict__ y = p.y[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int c = lane & 15;
@@ -251,35 +269,83 @@ __global__ void fold_bn_kernel(const float* __restrict__ W, const float* __restr
 
 using namespace dvq;
 
-extern "C" int dvq_linear(const float* x, int64_t ldx, const float* W, const float* b, int M, int K, int N, int relu,
-                          int add_identity3, float* y, int64_t ldy, void* stream) {
-    if (M < 0 || K < 1 || N < 1) return fail(DVQ_EINVAL, "linear: bad shape M=%d K=%d N=%d", M, K, N);
-    if (M == 0) return DVQ_OK;
-    if (!x || !W || !y) return fail(DVQ_EINVAL, "linear: null pointer");
-    if (ldx < K || ldy < N) return fail(DVQ_EINVAL, "linear: row stride smaller than the row");
-    if ((K % 4) != 0 || (ldx % 4) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)W & 15))
-        return fail(DVQ_EINVAL, "linear: K and ldx must be multiples of 4 and x, W 16-byte aligned");
-    if (add_identity3 && N != 9) return fail(DVQ_EINVAL, "linear: add_identity3 needs a 9-wide output");
-    hipStream_t st = as_stream(stream);
+static int linear_impl(const LinBatch& p, int nb, int64_t ldx, int M, int K, int N, int relu, int add_identity3, int64_t ldy,
+                       hipStream_t st) {
     if (M <= kSkinnyM) {
-        const int grid = (N + 3) / 4;
+        const dim3 grid((N + 3) / 4, nb);
         if (M <= 4)
-            hipLaunchKernelGGL((linear_skinny_kernel<4>), dim3(grid), dim3(256), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy);
+            hipLaunchKernelGGL((linear_skinny_kernel<4>), grid, dim3(256), 0, st, p, ldx, M, K, N, relu, add_identity3, ldy);
         else
-            hipLaunchKernelGGL((linear_skinny_kernel<kSkinnyM>), dim3(grid), dim3(256), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy);
+            hipLaunchKernelGGL((linear_skinny_kernel<kSkinnyM>), grid, dim3(256), 0, st, p, ldx, M, K, N, relu, add_identity3, ldy);
     } else {
         // the largest per-wave tile that still leaves every SIMD a wave (4 x 256 CUs)
         auto waves = [&](int rm, int rn) { return (int64_t)((M + 32 * rm - 1) / (32 * rm)) * ((N + 32 * rn - 1) / (32 * rn)); };
         const int64_t enough = 4 * kNumCU;
-#define DVQ_LIN_LAUNCH(RM, RN)                                                                                       \
-    hipLaunchKernelGGL((linear_kernel<RM, RN>), dim3((unsigned)((waves(RM, RN) + kLinWaves - 1) / kLinWaves)),      \
-                       dim3(kLinWaves * 64), 0, st, x, ldx, W, b, M, K, N, relu, add_identity3, y, ldy)
-        if (waves(2, 2) >= enough) DVQ_LIN_LAUNCH(2, 2);
-        else if (waves(2, 1) >= enough) DVQ_LIN_LAUNCH(2, 1);
+#define DVQ_LIN_LAUNCH(RM, RN)                                                                                            \
+    hipLaunchKernelGGL((linear_kernel<RM, RN>), dim3((unsigned)((waves(RM, RN) + kLinWaves - 1) / kLinWaves), nb),       \
+                       dim3(kLinWaves * 64), 0, st, p, ldx, M, K, N, relu, add_identity3, ldy)
+        if (waves(2, 2) * nb >= enough) DVQ_LIN_LAUNCH(2, 2);
+        else if (waves(2, 1) * nb >= enough) DVQ_LIN_LAUNCH(2, 1);
         else DVQ_LIN_LAUNCH(1, 1);
 #undef DVQ_LIN_LAUNCH
     }
     return check_launch("linear");
+}
+
+static int linear_bf16_impl(const LinBatch& p, int nb, int64_t ldx, int M, int K, int N, int relu, int64_t ldy, hipStream_t st) {
+    // the largest wave tile that still gives every CU a workgroup (the kernel is bound by the L2 -> CU traffic of its
+    // operands, which smaller tiles only raise: 64x64 per wave 0.125 ms at 4096x2560x1024, 32x64 0.157, 32x32 0.224)
+    auto blocks = [&](int rm, int rn) { return (int64_t)((M + 32 * rm - 1) / (32 * rm)) * ((N + 32 * rn - 1) / (32 * rn)); };
+#define DVQ_LINB_LAUNCH(RM, RN) \
+    hipLaunchKernelGGL((linear_bf16_kernel<RM, RN>), dim3((unsigned)blocks(RM, RN), nb), dim3(256), 0, st, p, ldx, M, K, N, relu, ldy)
+    if (blocks(4, 4) * nb >= kNumCU) DVQ_LINB_LAUNCH(4, 4);
+    else if (blocks(2, 4) * nb >= kNumCU) DVQ_LINB_LAUNCH(2, 4);
+    else DVQ_LINB_LAUNCH(2, 2);
+#undef DVQ_LINB_LAUNCH
+    return check_launch("linear_bf16");
+}
+
+static int linear_check(const float* x, const void* W, const float* y, int64_t ldx, int64_t ldy, int M, int K, int N, int add_identity3,
+                        bool bf16) {
+    if (!x || !W || !y) return fail(DVQ_EINVAL, "linear: null pointer");
+    if (ldx < K || ldy < N) return fail(DVQ_EINVAL, "linear: row stride smaller than the row");
+    if (bf16) {
+        if ((K % 32) != 0 || (ldx % 4) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)W & 15))
+            return fail(DVQ_EINVAL, "linear_bf16: K must be a multiple of 32, ldx of 4, and x, W 16-byte aligned");
+    } else {
+        if ((K % 4) != 0 || (ldx % 4) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)W & 15))
+            return fail(DVQ_EINVAL, "linear: K and ldx must be multiples of 4 and x, W 16-byte aligned");
+        if (add_identity3 && N != 9) return fail(DVQ_EINVAL, "linear: add_identity3 needs a 9-wide output");
+    }
+    return DVQ_OK;
+}
+
+extern "C" int dvq_linear(const float* x, int64_t ldx, const float* W, const float* b, int M, int K, int N, int relu,
+                          int add_identity3, float* y, int64_t ldy, void* stream) {
+    if (M < 0 || K < 1 || N < 1) return fail(DVQ_EINVAL, "linear: bad shape M=%d K=%d N=%d", M, K, N);
+    if (M == 0) return DVQ_OK;
+    if (int rc = linear_check(x, W, y, ldx, ldy, M, K, N, add_identity3, false)) return rc;
+    LinBatch p = {};
+    p.x[0] = x; p.W[0] = W; p.b[0] = b; p.y[0] = y;
+    return linear_impl(p, 1, ldx, M, K, N, relu, add_identity3, ldy, as_stream(stream));
+}
+
+extern "C" int dvq_linear_batched(int n_batch, const float* const* x, int64_t ldx, const void* const* W, const float* const* b,
+                                  int M, int K, int N, int relu, int add_identity3, float* const* y, int64_t ldy, int w_bf16,
+                                  void* stream) {
+    if (n_batch < 0 || n_batch > kLinMaxBatch) return fail(DVQ_EINVAL, "linear (batched): 0..%d products, got %d", kLinMaxBatch, n_batch);
+    if (M < 0 || K < 1 || N < 1) return fail(DVQ_EINVAL, "linear: bad shape M=%d K=%d N=%d", M, K, N);
+    if (M == 0 || n_batch == 0) return DVQ_OK;
+    if (!x || !W || !y) return fail(DVQ_EINVAL, "linear: null pointer");
+    if (w_bf16 && (add_identity3 || K < 32)) return fail(DVQ_EINVAL, "linear (batched): bf16 weights take K >= 32 and no identity");
+    LinBatch p = {};
+    for (int i = 0; i < n_batch; ++i) {
+        if (int rc = linear_check(x[i], W[i], y[i], ldx, ldy, M, K, N, add_identity3, w_bf16 != 0)) return rc;
+        p.x[i] = x[i]; p.W[i] = W[i]; p.b[i] = b ? b[i] : nullptr; p.y[i] = y[i];
+    }
+    hipStream_t st = as_stream(stream);
+    return w_bf16 ? linear_bf16_impl(p, n_batch, ldx, M, K, N, relu, ldy, st)
+                  : linear_impl(p, n_batch, ldx, M, K, N, relu, add_identity3, ldy, st);
 }
 
 extern "C" int dvq_fold_bn(const float* W, const float* b, const float* gamma, const float* beta, const float* mean,
@@ -305,20 +371,8 @@ extern "C" int dvq_linear_bf16(const float* x, int64_t ldx, const void* Wb, cons
                                int64_t ldy, void* stream) {
     if (M < 0 || K < 32 || N < 1) return fail(DVQ_EINVAL, "linear_bf16: bad shape M=%d K=%d N=%d", M, K, N);
     if (M == 0) return DVQ_OK;
-    if (!x || !Wb || !y) return fail(DVQ_EINVAL, "linear_bf16: null pointer");
-    if (ldx < K || ldy < N) return fail(DVQ_EINVAL, "linear_bf16: row stride smaller than the row");
-    if ((K % 32) != 0 || (ldx % 4) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)Wb & 15))
-        return fail(DVQ_EINVAL, "linear_bf16: K must be a multiple of 32, ldx of 4, and x, W 16-byte aligned");
-    hipStream_t st = as_stream(stream);
-    const unsigned short* W = reinterpret_cast<const unsigned short*>(Wb);
-    // the largest wave tile that still gives every CU a workgroup (the kernel is bound by the L2 -> CU traffic of its
-    // operands, which smaller tiles only raise: 64x64 per wave 0.125 ms at 4096x2560x1024, 32x64 0.157, 32x32 0.224)
-    auto blocks = [&](int rm, int rn) { return (int64_t)((M + 32 * rm - 1) / (32 * rm)) * ((N + 32 * rn - 1) / (32 * rn)); };
-#define DVQ_LINB_LAUNCH(RM, RN) \
-    hipLaunchKernelGGL((linear_bf16_kernel<RM, RN>), dim3((unsigned)blocks(RM, RN)), dim3(256), 0, st, x, ldx, W, b, M, K, N, relu, y, ldy)
-    if (blocks(4, 4) >= kNumCU) DVQ_LINB_LAUNCH(4, 4);
-    else if (blocks(2, 4) >= kNumCU) DVQ_LINB_LAUNCH(2, 4);
-    else DVQ_LINB_LAUNCH(2, 2);
-#undef DVQ_LINB_LAUNCH
-    return check_launch("linear_bf16");
+    if (int rc = linear_check(x, Wb, y, ldx, ldy, M, K, N, 0, true)) return rc;
+    LinBatch p = {};
+    p.x[0] = x; p.W[0] = Wb; p.b[0] = b; p.y[0] = y;
+    return linear_bf16_impl(p, 1, ldx, M, K, N, relu, ldy, as_stream(stream));
 }

@@ -150,11 +150,35 @@ __device__ __forceinline__ void pn_point_tile(const float* __restrict__ xb_, int
     }
 }
 
+// Arguments of up to kPnMaxGroups independent launches folded into one grid (dvq_pointnet_mlp_max_grouped): group g owns
+// the workgroups block_start[g] .. block_start[g+1]-1.
+constexpr int kPnMaxGroups = 8;
+struct PnGroupsDev {
+    const float* x[kPnMaxGroups];
+    const float* trans[kPnMaxGroups];
+    const float* a1[kPnMaxGroups];
+    const float* c1[kPnMaxGroups];
+    const float* a2[kPnMaxGroups];
+    const float* c2[kPnMaxGroups];
+    const char* w3p[kPnMaxGroups];
+    const float* c3[kPnMaxGroups];
+    float* feat[kPnMaxGroups];
+    int N[kPnMaxGroups], B[kPnMaxGroups], cpb[kPnMaxGroups], relu3[kPnMaxGroups];
+    int block_start[kPnMaxGroups + 1];
+    int n;
+};
+__device__ __forceinline__ int pn_group_of(const PnGroupsDev& g, int block) {
+    int k = 0;
+    while (k + 1 < g.n && block >= g.block_start[k + 1]) ++k;
+    return __builtin_amdgcn_readfirstlane(k);
+}
+
 template <int DT, int C>
-__global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp_max_kernel(
+__device__ __forceinline__ void pn_body(
     const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
     const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
-    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb) {
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb,
+    int block_id) {
     typedef PnCfg<DT> Cfg;
     constexpr int NP = Cfg::NP;
     constexpr int STAGE_BYTES = Cfg::CPS * Cfg::UPC * 1024;
@@ -180,7 +204,7 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
     const int h = lane >> 5;
     const int cl = wave / wpc;                            // this wave's cloud within the block
     const int lw = wave - cl * wpc;
-    int b = blockIdx.x * cpb + cl;
+    int b = block_id * cpb + cl;
     if (b >= B) b = B - 1;                                // a surplus slot recomputes the last cloud; its result is not stored
     int* wmax = bmax + cl * kC3;
 
@@ -296,12 +320,26 @@ __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp
     // ---- epilogue: bias (and ReLU for the STN trunk) after the max -- both are monotone,
     // so max_n act(h_n + c) == act(max_n h_n + c) exactly.
     for (int i = tid; i < cpb * kC3; i += kPnThreads) {
-        const int cloud = blockIdx.x * cpb + i / kC3, ch = i % kC3;
+        const int cloud = block_id * cpb + i / kC3, ch = i % kC3;
         if (cloud >= B) break;
         float v = key_f32(bmax[i]) + c3[ch];
         if (relu3) v = v > 0.f ? v : 0.f;
         feat[(int64_t)cloud * kC3 + ch] = v;
     }
+}
+
+template <int DT, int C>
+__global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp_max_kernel(
+    const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
+    const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb) {
+    pn_body<DT, C>(x, trans, N, a1, c1, a2, c2, w3p, c3, relu3, feat, B, cpb, blockIdx.x);
+}
+template <int DT, int C>
+__global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp_max_grouped_kernel(PnGroupsDev g) {
+    const int k = pn_group_of(g, blockIdx.x);
+    pn_body<DT, C>(g.x[k], g.trans[k], g.N[k], g.a1[k], g.c1[k], g.a2[k], g.c2[k], g.w3p[k], g.c3[k], g.relu3[k], g.feat[k],
+                   g.B[k], g.cpb[k], blockIdx.x - g.block_start[k]);
 }
 
 // ------------------------------------------------------------------ bf16, 16x16x32 tiles
@@ -396,10 +434,11 @@ __device__ __forceinline__ void pn_point_tile16(const float* __restrict__ xb, in
 }
 
 template <int C>
-__global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_kernel(
+__device__ __forceinline__ void pn16_body(
     const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
     const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
-    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb) {
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb,
+    int block_id) {
     constexpr int NP = kPnNP16;
     constexpr int STAGE_BYTES = kPnCPS16 * kPnUPC16 * 1024;
     constexpr int N_STAGES = kCt16 / kPnCPS16;
@@ -421,7 +460,7 @@ __global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_kernel(
     const int q = lane >> 4;
     const int cl = wave / wpc;                            // this wave's cloud within the block
     const int lw = wave - cl * wpc;
-    int b = blockIdx.x * cpb + cl;
+    int b = block_id * cpb + cl;
     if (b >= B) b = B - 1;                                // a surplus slot recomputes the last cloud; its result is not stored
     float* wmax = bmax + cl * kC3;
 
@@ -528,12 +567,26 @@ __global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_kernel(
     }
 
     for (int i = tid; i < cpb * kC3; i += kPnThreads) {
-        const int cloud = blockIdx.x * cpb + i / kC3, ch = i % kC3;
+        const int cloud = block_id * cpb + i / kC3, ch = i % kC3;
         if (cloud >= B) break;
         float v = bmax[i] + c3[ch];
         if (relu3) v = v > 0.f ? v : 0.f;
         feat[(int64_t)cloud * kC3 + ch] = v;
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
+    const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb) {
+    pn16_body<C>(x, trans, N, a1, c1, a2, c2, w3p, c3, relu3, feat, B, cpb, blockIdx.x);
+}
+template <int C>
+__global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_grouped_kernel(PnGroupsDev g) {
+    const int k = pn_group_of(g, blockIdx.x);
+    pn16_body<C>(g.x[k], g.trans[k], g.N[k], g.a1[k], g.c1[k], g.a2[k], g.c2[k], g.w3p[k], g.c3[k], g.relu3[k], g.feat[k], g.B[k],
+                 g.cpb[k], blockIdx.x - g.block_start[k]);
 }
 
 template <int DT>
@@ -542,12 +595,21 @@ static size_t pn_lds_bytes(int cpb) {
     return 2 * (size_t)Cfg::CPS * Cfg::UPC * 1024 + (size_t)Cfg::A2_UNITS * 1024 + (kC1 * 4 + kC1 + kC2) * 4 + (size_t)cpb * kC3 * 4;
 }
 
+static int pn_cpb(int N, int pts_per_wave) {
+    // clouds per workgroup: as many as fit a chunk of 8 waves x pts_per_wave points, at most 4 (LDS for the running maxima)
+    int cpb = 1;
+    while (cpb < 4 && N <= (kPnWaves / (2 * cpb)) * pts_per_wave) cpb *= 2;
+    return cpb;
+}
+static size_t pn_lds_bytes16(int cpb) {
+    return 2 * (size_t)kPnCPS16 * kPnUPC16 * 1024 + 16 * 1024 + (kC1 * 4 + kC1 + kC2) * 4 + (size_t)cpb * kC3 * 4;
+}
+
 template <int C>
 static int pn_launch16(const float* x, const float* trans, int B, int N, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
     auto kern = pointnet_mlp_max_bf16_kernel<C>;
-    int cpb = 1;
-    while (cpb < 4 && N <= (kPnWaves / (2 * cpb)) * kPnNP16 * 16) cpb *= 2;
-    const size_t lds = 2 * (size_t)kPnCPS16 * kPnUPC16 * 1024 + 16 * 1024 + (kC1 * 4 + kC1 + kC2) * 4 + (size_t)cpb * kC3 * 4;
+    const int cpb = pn_cpb(N, kPnNP16 * 16);
+    const size_t lds = pn_lds_bytes16(cpb);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "pointnet_mlp_max")) return rc;
     hipLaunchKernelGGL(kern, dim3((B + cpb - 1) / cpb), dim3(kPnThreads), lds, st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
                        reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat, B, cpb);
@@ -557,15 +619,49 @@ static int pn_launch16(const float* x, const float* trans, int B, int N, const D
 template <int DT, int C>
 static int pn_launch(const float* x, const float* trans, int B, int N, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
     auto kern = pointnet_mlp_max_kernel<DT, C>;
-    // clouds per workgroup: as many as fit a chunk of 8 waves x NP x 32 points, at most 4 (LDS for the running maxima)
-    const int pts_per_wave = PnCfg<DT>::NP * 32;
-    int cpb = 1;
-    while (cpb < 4 && N <= (kPnWaves / (2 * cpb)) * pts_per_wave) cpb *= 2;
+    const int cpb = pn_cpb(N, PnCfg<DT>::NP * 32);
     const size_t lds = pn_lds_bytes<DT>(cpb);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "pointnet_mlp_max")) return rc;
     hipLaunchKernelGGL(kern, dim3((B + cpb - 1) / cpb), dim3(kPnThreads), lds, st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
                        reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat, B, cpb);
     return check_launch("pointnet_mlp_max");
+}
+
+// Vertex subsets of a point set, all parts in one launch: part k of cloud b is written as a contiguous [3, n_k] block
+// of the k-th output segment.  With `center` the per-axis mean over ALL V points is subtracted first (DVQVAE.py:49-51).
+__global__ __launch_bounds__(256) void gather_parts_kernel(const float* __restrict__ pts, int B, int V, const int* __restrict__ idx,
+                                                           const int* __restrict__ part_ptr, int P, int center,
+                                                           float* __restrict__ out) {
+    __shared__ float red[3][4];
+    __shared__ float mean[3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = pts + (int64_t)b * 3 * V;
+    if (center) {
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int v = tid; v < V; v += 256)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] += src[a * V + v];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float t = acc[a];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane == 0) red[a][wave] = t;
+        }
+        __syncthreads();
+        if (tid < 3) mean[tid] = (red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3]) / (float)V;
+    } else if (tid < 3) {
+        mean[tid] = 0.f;
+    }
+    __syncthreads();
+    const int total = part_ptr[P];
+    for (int t = tid; t < 3 * total; t += 256) {
+        const int a = t / total, j = t - a * total;
+        int k = 0;
+        while (k + 1 < P && j >= part_ptr[k + 1]) ++k;
+        const int n_k = part_ptr[k + 1] - part_ptr[k];
+        out[(int64_t)3 * B * part_ptr[k] + ((int64_t)b * 3 + a) * n_k + (j - part_ptr[k])] = src[a * V + idx[j]] - mean[a];
+    }
 }
 
 }  // namespace dvq
@@ -611,4 +707,65 @@ extern "C" int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, i
                       : pn_launch<DVQ_F32, 4>(x, trans, B, N, w, relu3, feat_out, st);
     }
     return fail(DVQ_EINVAL, "pointnet: unknown dtype %d", dtype);
+}
+
+extern "C" int dvq_pointnet_mlp_max_grouped(const DvqPointGroup* groups, int n_groups, int C, int dtype, void* stream) {
+    if (n_groups < 0 || n_groups > kPnMaxGroups) return fail(DVQ_EINVAL, "pointnet (grouped): 0..%d groups, got %d", kPnMaxGroups, n_groups);
+    if (C != 3 && C != 4) return fail(DVQ_EINVAL, "pointnet: C must be 3 or 4 (got %d)", C);
+    if (dtype != DVQ_BF16 && dtype != DVQ_F32) return fail(DVQ_EINVAL, "pointnet: unknown dtype %d", dtype);
+    if (n_groups && !groups) return fail(DVQ_EINVAL, "pointnet: null pointer");
+    PnGroupsDev g;
+    g.n = 0;
+    int blocks = 0, max_cpb = 1;
+    const int pts_per_wave = dtype == DVQ_BF16 ? kPnNP16 * 16 : PnCfg<DVQ_F32>::NP * 32;
+    for (int i = 0; i < n_groups; ++i) {
+        const DvqPointGroup& s = groups[i];
+        if (s.B < 0 || s.N < 1) return fail(DVQ_EINVAL, "pointnet: bad shape B=%d N=%d in group %d", s.B, s.N, i);
+        if (s.B == 0) continue;
+        if (!s.x || !s.feat_out) return fail(DVQ_EINVAL, "pointnet: null pointer in group %d", i);
+        const DvqPointMlp& w = s.w;
+        if (!w.a1 || !w.c1 || !w.a2 || !w.c2 || !w.w3p || !w.c3) return fail(DVQ_EINVAL, "pointnet: null weight pointer in group %d", i);
+        if (((uintptr_t)w.a2 & 15) || ((uintptr_t)w.w3p & 15)) return fail(DVQ_EINVAL, "pointnet: a2 and w3p must be 16-byte aligned");
+        const int k = g.n++;
+        g.x[k] = s.x; g.trans[k] = s.trans; g.a1[k] = w.a1; g.c1[k] = w.c1; g.a2[k] = w.a2; g.c2[k] = w.c2;
+        g.w3p[k] = reinterpret_cast<const char*>(w.w3p); g.c3[k] = w.c3; g.feat[k] = s.feat_out;
+        g.N[k] = s.N; g.B[k] = s.B; g.relu3[k] = s.relu3;
+        g.cpb[k] = pn_cpb(s.N, pts_per_wave);
+        if (g.cpb[k] > max_cpb) max_cpb = g.cpb[k];
+        g.block_start[k] = blocks;
+        blocks += (s.B + g.cpb[k] - 1) / g.cpb[k];
+    }
+    if (g.n == 0) return DVQ_OK;
+    g.block_start[g.n] = blocks;
+    for (int k = g.n; k < kPnMaxGroups; ++k) {   // unused slots: defined values
+        g.x[k] = nullptr; g.trans[k] = nullptr; g.a1[k] = g.c1[k] = g.a2[k] = g.c2[k] = g.c3[k] = nullptr; g.w3p[k] = nullptr;
+        g.feat[k] = nullptr; g.N[k] = g.B[k] = g.relu3[k] = 0; g.cpb[k] = 1;
+        if (k > g.n) g.block_start[k] = blocks;
+    }
+    hipStream_t st = as_stream(stream);
+#define DVQ_PN_GROUPED(KERN, LDS)                                                                            \
+    do {                                                                                                     \
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(KERN), LDS, "pointnet_mlp_max")) return rc; \
+        hipLaunchKernelGGL(KERN, dim3(blocks), dim3(kPnThreads), LDS, st, g);                                \
+    } while (0)
+    if (dtype == DVQ_BF16) {
+        const size_t lds = pn_lds_bytes16(max_cpb);
+        if (C == 3) DVQ_PN_GROUPED(pointnet_mlp_max_bf16_grouped_kernel<3>, lds);
+        else DVQ_PN_GROUPED(pointnet_mlp_max_bf16_grouped_kernel<4>, lds);
+    } else {
+        const size_t lds = pn_lds_bytes<DVQ_F32>(max_cpb);
+        if (C == 3) DVQ_PN_GROUPED((pointnet_mlp_max_grouped_kernel<DVQ_F32, 3>), lds);
+        else DVQ_PN_GROUPED((pointnet_mlp_max_grouped_kernel<DVQ_F32, 4>), lds);
+    }
+#undef DVQ_PN_GROUPED
+    return check_launch("pointnet_mlp_max(grouped)");
+}
+
+extern "C" int dvq_gather_parts(const float* pts, int B, int V, const int* idx, const int* part_ptr, int n_parts, int center,
+                                float* out, void* stream) {
+    if (B < 0 || V < 1 || n_parts < 1) return fail(DVQ_EINVAL, "gather_parts: bad shape B=%d V=%d parts=%d", B, V, n_parts);
+    if (B == 0) return DVQ_OK;
+    if (!pts || !idx || !part_ptr || !out) return fail(DVQ_EINVAL, "gather_parts: null pointer");
+    hipLaunchKernelGGL(gather_parts_kernel, dim3(B), dim3(256), 0, as_stream(stream), pts, B, V, idx, part_ptr, n_parts, center, out);
+    return check_launch("gather_parts");
 }

@@ -42,6 +42,15 @@ __device__ __host__ __forceinline__ int vq_dim_f32(int s, int h, int i, int D) {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Operands of up to kVqMaxBatch searches of one shape folded into one grid (blockIdx.y picks the search).
+constexpr int kVqMaxBatch = 8;
+struct VqBatch {
+    const void* z[kVqMaxBatch];
+    const char* packed[kVqMaxBatch];
+    const float* e2[kVqMaxBatch];
+    int64_t* idx[kVqMaxBatch];
+};
+
 constexpr int kVqRotMinTiles = 8;          // 256 codes: four stages of two tiles
 constexpr int kVqRotMaxTiles = 64;
 constexpr int64_t kVqRotMinRows = 65536;   // below this the one-sweep kernel has the lower fixed cost
@@ -127,9 +136,11 @@ __device__ __forceinline__ void stage_copy(const char* __restrict__ src, char* d
 // the codebook.  The codebook streams through LDS in stages of TS tiles (double
 // buffered when there is more than one stage).
 template <int DT, int D, int NB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void vq_argmin_reg_kernel(
-    const typename VqTraits<DT>::elem* __restrict__ z, const char* __restrict__ packed,
-    const float* __restrict__ e2, int64_t n, int n_tiles, int TS, int64_t* __restrict__ idx_out) {
+__global__ __launch_bounds__(WAVES * 64) void vq_argmin_reg_kernel(VqBatch vb, int64_t n, int n_tiles, int TS) {
+    const typename VqTraits<DT>::elem* __restrict__ z = reinterpret_cast<const typename VqTraits<DT>::elem*>(vb.z[blockIdx.y]);
+    const char* __restrict__ packed = vb.packed[blockIdx.y];
+    const float* __restrict__ e2 = vb.e2[blockIdx.y];
+    int64_t* __restrict__ idx_out = vb.idx[blockIdx.y];
     constexpr int U = D / VqTraits<DT>::kDimsPerUnit;       // 1-KiB units per code tile
     constexpr int TILE_BYTES = U * 1024;
     constexpr int ZR = (DT == DVQ_BF16) ? U : U * 4;        // fragment registers-groups per latent block
@@ -304,9 +315,10 @@ __global__ void vq_pack_bf16x_kernel(const unsigned short* __restrict__ E, int K
 // bytes per latent row and instruction when loading z -- and, in the accumulator, codes 4q..4q+3
 // of the 16-code tile.
 template <int D, int NB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_kernel(
-    const unsigned short* __restrict__ z, const char* __restrict__ packed, int64_t n, int n_tiles, int TS,
-    int64_t* __restrict__ idx_out) {
+__global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_kernel(VqBatch vb, int64_t n, int n_tiles, int TS) {
+    const unsigned short* __restrict__ z = reinterpret_cast<const unsigned short*>(vb.z[blockIdx.y]);
+    const char* __restrict__ packed = vb.packed[blockIdx.y];
+    int64_t* __restrict__ idx_out = vb.idx[blockIdx.y];
     constexpr int S = D / 32;
     constexpr int TILE_BYTES = (2 * S + 1) * 1024;   // a group of 32 codes
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -850,7 +862,7 @@ static bool vq_plan(int K, int D, int dtype, VqPlan* p) {
 }
 
 template <int DT, int D, int NB, int WAVES>
-static int launch_reg(const void* z, const char* ws, const VqPlan& p, int64_t n, int64_t* idx_out, hipStream_t st) {
+static int launch_reg(const VqBatch& vb, int nb, const VqPlan& p, int64_t n, hipStream_t st) {
     constexpr int U = D / VqTraits<DT>::kDimsPerUnit;
     constexpr int TILE_BYTES = U * 1024;
     int TS = 65536 / TILE_BYTES;  // 64 KiB of codebook per stage
@@ -862,16 +874,15 @@ static int launch_reg(const void* z, const char* ws, const VqPlan& p, int64_t n,
     auto kern = vq_argmin_reg_kernel<DT, D, NB, WAVES>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "vq_argmin")) return rc;
     const int64_t groups = (n + WAVES * NB * 32 - 1) / (WAVES * NB * 32);
-    const int64_t max_blocks = (lds > 80 * 1024) ? kNumCU : 2 * kNumCU;
+    int64_t max_blocks = ((lds > 80 * 1024) ? kNumCU : 2 * kNumCU) / nb;   // searches of a batch share the CUs
+    if (max_blocks < 1) max_blocks = 1;
     const int grid = (int)(groups < max_blocks ? groups : max_blocks);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st,
-                       reinterpret_cast<const typename VqTraits<DT>::elem*>(z), ws, reinterpret_cast<const float*>(ws + p.e2_off),
-                       n, p.n_tiles, TS, idx_out);
+    hipLaunchKernelGGL(kern, dim3(grid, nb), dim3(WAVES * 64), lds, st, vb, n, p.n_tiles, TS);
     return check_launch("vq_argmin");
 }
 
 template <int D, int NB, int WAVES>
-static int launch_bf16x(const void* z, const char* ws, const VqPlan& p, int64_t n, int64_t* idx_out, hipStream_t st) {
+static int launch_bf16x(const VqBatch& vb, int nb, const VqPlan& p, int64_t n, hipStream_t st) {
     constexpr int TILE_BYTES = (D / 16 + 1) * 1024;
     int TS = (68 * 1024) / TILE_BYTES;   // 68-KiB stages: 4 groups of 32 codes at D=256
     if (TS < 1) TS = 1;
@@ -881,9 +892,10 @@ static int launch_bf16x(const void* z, const char* ws, const VqPlan& p, int64_t 
     auto kern = vq_argmax_bf16_kernel<D, NB, WAVES>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "vq_argmin")) return rc;
     const int64_t groups = (n + WAVES * NB * 16 - 1) / (WAVES * NB * 16);
-    const int64_t max_blocks = (lds > 80 * 1024) ? kNumCU : 2 * kNumCU;
+    int64_t max_blocks = ((lds > 80 * 1024) ? kNumCU : 2 * kNumCU) / nb;
+    if (max_blocks < 1) max_blocks = 1;
     const int grid = (int)(groups < max_blocks ? groups : max_blocks);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, reinterpret_cast<const unsigned short*>(z), ws, n, p.n_tiles, TS, idx_out);
+    hipLaunchKernelGGL(kern, dim3(grid, nb), dim3(WAVES * 64), lds, st, vb, n, p.n_tiles, TS);
     return check_launch("vq_argmin(bf16)");
 }
 
@@ -902,6 +914,19 @@ static int launch_bf16_rot(const void* z, const char* ws, const VqPlan& p, int64
     return check_launch("vq_argmin(bf16, rotating)");
 }
 
+// the register-resident kernels (D = 64, 128, 256), one search or a batch of searches of one shape
+template <int DT>
+static int launch_fast(const VqBatch& vb, int nb, const VqPlan& p, int64_t n, int D, hipStream_t st) {
+    if (DT == DVQ_BF16) {
+        if (D == 256) return launch_bf16x<256, 4, 8>(vb, nb, p, n, st);
+        if (D == 128) return launch_bf16x<128, 4, 8>(vb, nb, p, n, st);
+        return launch_bf16x<64, 4, 8>(vb, nb, p, n, st);
+    }
+    if (D == 256) return launch_reg<DVQ_F32, 256, 1, 8>(vb, nb, p, n, st);
+    if (D == 128) return launch_reg<DVQ_F32, 128, 2, 8>(vb, nb, p, n, st);
+    return launch_reg<DVQ_F32, 64, 2, 8>(vb, nb, p, n, st);
+}
+
 template <int DT>
 static int launch_search(const void* z, const char* ws, const VqPlan& p, int64_t n, int D, int64_t* idx_out, hipStream_t st) {
     if (n == 0) return DVQ_OK;
@@ -909,13 +934,11 @@ static int launch_search(const void* z, const char* ws, const VqPlan& p, int64_t
         // 256 to 2048 codes and enough latents for every wave to keep four tiles in rotation (measured: 1.2x at 256
         // codes, 1.14x at 512, 1.07x at 1024, even at 2048, behind the one-sweep kernel at 8192)
         if (D == 256 && p.n_tiles >= kVqRotMinTiles && p.n_tiles <= kVqRotMaxTiles && n >= kVqRotMinRows) return launch_bf16_rot<256, 8>(z, ws, p, n, idx_out, st);
-        if (D == 256) return launch_bf16x<256, 4, 8>(z, ws, p, n, idx_out, st);
-        if (D == 128) return launch_bf16x<128, 4, 8>(z, ws, p, n, idx_out, st);
-        if (D == 64) return launch_bf16x<64, 4, 8>(z, ws, p, n, idx_out, st);
-    } else {
-        if (D == 256) return launch_reg<DVQ_F32, 256, 1, 8>(z, ws, p, n, idx_out, st);
-        if (D == 128) return launch_reg<DVQ_F32, 128, 2, 8>(z, ws, p, n, idx_out, st);
-        if (D == 64) return launch_reg<DVQ_F32, 64, 2, 8>(z, ws, p, n, idx_out, st);
+    }
+    if (D == 256 || D == 128 || D == 64) {
+        VqBatch vb = {};
+        vb.z[0] = z; vb.packed[0] = ws; vb.e2[0] = reinterpret_cast<const float*>(ws + p.e2_off); vb.idx[0] = idx_out;
+        return launch_fast<DT>(vb, 1, p, n, D, st);
     }
     // long rows, many latents
     if (n > (int64_t)32 * 4 * kNumCU && (D % (16 * VqTraits<DT>::kDimsPerUnit)) == 0) {
@@ -1034,6 +1057,31 @@ extern "C" int dvq_vq_argmin_prepared(const void* z, const void* E, int64_t n, i
     rc = (dtype == DVQ_BF16) ? launch_search<DVQ_BF16>(z, ws, p, n, D, idx_out, st) : launch_search<DVQ_F32>(z, ws, p, n, D, idx_out, st);
     if (rc) return rc;
     if (zq_out) return vq_gather_impl(idx_out, E, n, K, D, dtype, zq_out, D, st);
+    return DVQ_OK;
+}
+
+extern "C" int dvq_vq_argmin_prepared_batched(int n_batch, const void* const* z, const void* const* E, int64_t n, int K, int D,
+                                              int dtype, int64_t* const* idx_out, const void* const* workspace, void* stream) {
+    if (n_batch < 0 || n_batch > kVqMaxBatch) return fail(DVQ_EINVAL, "vq (batched): 0..%d searches, got %d", kVqMaxBatch, n_batch);
+    if (n_batch == 0) return DVQ_OK;
+    if (!z || !E || !idx_out || !workspace) return fail(DVQ_EINVAL, "vq: null pointer");
+    VqPlan p;
+    VqBatch vb = {};
+    for (int i = 0; i < n_batch; ++i) {
+        if (int rc = vq_check(z[i], E[i], n, K, D, dtype, idx_out[i], workspace[i], &p)) return rc;
+        const char* ws = reinterpret_cast<const char*>(workspace[i]);
+        vb.z[i] = z[i]; vb.packed[i] = ws; vb.e2[i] = reinterpret_cast<const float*>(ws + p.e2_off); vb.idx[i] = idx_out[i];
+    }
+    if (n == 0) return DVQ_OK;
+    hipStream_t st = as_stream(stream);
+    const bool rot = dtype == DVQ_BF16 && D == 256 && p.n_tiles >= kVqRotMinTiles && p.n_tiles <= kVqRotMaxTiles && n >= kVqRotMinRows;
+    if ((D == 256 || D == 128 || D == 64) && !rot)
+        return dtype == DVQ_BF16 ? launch_fast<DVQ_BF16>(vb, n_batch, p, n, D, st) : launch_fast<DVQ_F32>(vb, n_batch, p, n, D, st);
+    for (int i = 0; i < n_batch; ++i) {   // shapes without a batched kernel: one launch each
+        const int rc = dtype == DVQ_BF16 ? launch_search<DVQ_BF16>(z[i], vb.packed[i], p, n, D, idx_out[i], st)
+                                         : launch_search<DVQ_F32>(z[i], vb.packed[i], p, n, D, idx_out[i], st);
+        if (rc) return rc;
+    }
     return DVQ_OK;
 }
 

@@ -22,6 +22,11 @@ class DvqPointMlp(ctypes.Structure):
                 ("w3p", c_void_p), ("c3", c_void_p)]
 
 
+class DvqPointGroup(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("trans", c_void_p), ("B", c_int), ("N", c_int), ("w", DvqPointMlp), ("relu3", c_int),
+                ("feat_out", c_void_p)]
+
+
 class DvqManoConsts(ctypes.Structure):
     _fields_ = [("n_verts", c_int), ("n_comps", c_int), ("v_shaped", c_void_p), ("joints", c_void_p),
                 ("posedirs", c_void_p), ("lbs_weights", c_void_p), ("components", c_void_p),
@@ -57,12 +62,18 @@ SIGNATURES = {
     "dvq_vq_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvq_vq_argmin": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvq_vq_argmin_prepared": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dvq_vq_argmin_prepared_batched": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_int64, c_int, c_int, c_int,
+                                               POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     "dvq_vq_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "dvq_pointnet_w3_bytes": (c_size_t, [c_int]),
     "dvq_pointnet_pack_w3": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "dvq_pointnet_mlp_max": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DvqPointMlp), c_int, c_int, c_void_p, c_void_p]),
+    "dvq_pointnet_mlp_max_grouped": (c_int, [POINTER(DvqPointGroup), c_int, c_int, c_int, c_void_p]),
+    "dvq_gather_parts": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dvq_fold_bn": (c_int, [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dvq_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "dvq_linear_batched": (c_int, [c_int, POINTER(c_void_p), c_int64, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int,
+                                   c_int, c_int, POINTER(c_void_p), c_int64, c_int, c_void_p]),
     "dvq_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "dvq_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "dvq_prior_packed_bytes": (c_size_t, [c_int, c_int]),

@@ -112,6 +112,27 @@ def vq_argmin(z: torch.Tensor, E: torch.Tensor, want_zq: bool = True,
     return idx, zq
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def vq_argmin_batched(zs, Es, prepared) -> list:
+    """Indices (int64 [n] each) of several searches of one shape -- own latents, codebook and prepared workspace
+    each -- in one launch (up to 8)."""
+    _need_gpu(*zs, *Es, *prepared)
+    n, D = zs[0].shape
+    K = Es[0].shape[0]
+    for z, E in zip(zs, Es):
+        if z.shape != (n, D) or E.shape != (K, D) or z.dtype != Es[0].dtype or E.dtype != Es[0].dtype or not z.is_contiguous():
+            raise RuntimeError("vq_argmin_batched: all searches must have one shape and dtype, contiguous latents")
+    idx = [torch.empty(n, dtype=torch.int64, device=zs[0].device) for _ in zs]
+    with torch.cuda.device(zs[0].device):
+        rc = _lib.load().dvq_vq_argmin_prepared_batched(len(zs), _ptr_array(zs), _ptr_array(Es), n, K, D, _dtype_code(zs[0]),
+                                                        _ptr_array(idx), _ptr_array(prepared), _stream(zs[0]))
+    _lib.check(rc, "dvq_vq_argmin_prepared_batched")
+    return idx
+
+
 def vq_gather(idx: torch.Tensor, E: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[b] = E[idx[b]] (fp32).  `out` may be a column slice of a wider row-major buffer."""
     _need_gpu(idx, E)
@@ -168,6 +189,49 @@ def pointnet_mlp_max(x: torch.Tensor, trans: Optional[torch.Tensor], w: dict, re
     return feat
 
 
+def pointnet_mlp_max_grouped(groups, dtype_code: int) -> list:
+    """Several pointnet_mlp_max calls of one channel count as one launch (up to 8).
+    groups: list of (x [B,C,N], trans or None, w dict, relu3); returns the [B,1024] features."""
+    structs = (_lib.DvqPointGroup * len(groups))()
+    feats = []
+    C = groups[0][0].shape[1]
+    for i, (x, trans, w, relu3) in enumerate(groups):
+        _need_gpu(x, trans, w["a1"], w["c1"], w["a2"], w["c2"], w["w3p"], w["c3"])
+        if x.shape[1] != C or not x.is_contiguous() or (trans is not None and not trans.is_contiguous()):
+            raise RuntimeError("pointnet_mlp_max_grouped: one channel count for all groups, contiguous tensors")
+        B, _, N = x.shape
+        feat = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
+        feats.append(feat)
+        structs[i] = _lib.DvqPointGroup(x.data_ptr(), None if trans is None else trans.data_ptr(), B, N,
+                                        DvqPointMlp(w["a1"].data_ptr(), w["c1"].data_ptr(), w["a2"].data_ptr(), w["c2"].data_ptr(),
+                                                    w["w3p"].data_ptr(), w["c3"].data_ptr()), int(relu3), feat.data_ptr())
+    x0 = groups[0][0]
+    with torch.cuda.device(x0.device):
+        rc = _lib.load().dvq_pointnet_mlp_max_grouped(structs, len(groups), C, dtype_code, _stream(x0))
+    _lib.check(rc, "dvq_pointnet_mlp_max_grouped")
+    return feats
+
+
+def gather_parts(pts: torch.Tensor, idx: torch.Tensor, part_ptr: torch.Tensor, sizes, center: bool) -> list:
+    """Vertex subsets of pts [B,3,V] (optionally centred on the mean over all V first), all parts in one launch.
+    idx int32: the index lists back to back; part_ptr int32 [P+1]: their offsets (both on the device); sizes: the P
+    list lengths (host).  Returns P contiguous tensors [B,3,n_k] (views of one buffer)."""
+    _need_gpu(pts, idx, part_ptr)
+    if pts.dim() != 3 or pts.shape[1] != 3 or not pts.is_contiguous() or idx.dtype != torch.int32 or part_ptr.dtype != torch.int32:
+        raise RuntimeError("gather_parts: pts must be contiguous [B,3,V]; idx and part_ptr int32")
+    B, _, V = pts.shape
+    total = int(sum(sizes))
+    out = torch.empty(3 * B * total, dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        rc = _lib.load().dvq_gather_parts(_p(pts), B, V, _p(idx), _p(part_ptr), len(sizes), int(center), _p(out), _stream(pts))
+    _lib.check(rc, "dvq_gather_parts")
+    parts, off = [], 0
+    for n_k in sizes:
+        parts.append(out[3 * B * off: 3 * B * (off + n_k)].view(B, 3, n_k))
+        off += n_k
+    return parts
+
+
 # ----------------------------------------------------------------------- linear
 # below this many rows the fp32 kernels are bound by latency, not by the matrix cores, and bf16 operands buy nothing
 LINEAR_BF16_MIN_ROWS = 512
@@ -213,6 +277,27 @@ def linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], relu: bo
         rc = _lib.load().dvq_linear(_p(x), ldx, _p(W), _p(b), M, K, N, int(relu), int(add_identity3), _p(out), ldy, _stream(x))
     _lib.check(rc, "dvq_linear")
     return out
+
+
+def linear_batched(xs, Ws, bs, relu: bool = False, add_identity3: bool = False, Ws_bf16=None) -> list:
+    """Several linear() calls of one shape -- own x [M,K], W [N,K], b each -- as one launch (up to 8).  With bf16 copies of
+    the weights and a shape the bf16 kernel takes, the products run on bf16 operands as in linear()."""
+    _need_gpu(*xs, *Ws, *[b for b in bs if b is not None])
+    M, K = xs[0].shape
+    N = Ws[0].shape[0]
+    for x, W in zip(xs, Ws):
+        if x.shape != (M, K) or W.shape != (N, K) or x.stride(-1) != 1 or x.stride(0) != xs[0].stride(0):
+            raise RuntimeError("linear_batched: all products must have one shape and row stride")
+    use_bf16 = (Ws_bf16 is not None and all(w is not None for w in Ws_bf16) and not add_identity3
+                and M >= LINEAR_BF16_MIN_ROWS and K % 32 == 0 and N >= 64)
+    outs = [torch.empty(M, N, dtype=torch.float32, device=xs[0].device) for _ in xs]
+    ldx = xs[0].stride(0) if M > 1 else max(K, xs[0].stride(0))
+    with torch.cuda.device(xs[0].device):
+        rc = _lib.load().dvq_linear_batched(len(xs), _ptr_array(xs), ldx, _ptr_array(Ws_bf16 if use_bf16 else Ws), _ptr_array(bs),
+                                            M, K, N, int(relu), int(add_identity3), _ptr_array(outs), N, int(use_bf16),
+                                            _stream(xs[0]))
+    _lib.check(rc, "dvq_linear_batched")
+    return outs
 
 
 # ------------------------------------------------------------------------- MANO

@@ -13,22 +13,26 @@ import torch
 import torch.nn as nn
 
 from dvq_hip import ops
+from dvq_hip._lib import DVQ_BF16, DVQ_F32
 from dvq_hip.hand_parts import HAND_PARTS
 from network.pointnet_encoder import PointNetEncoder
 from network.VQVAE import VQVAE
 
 
-def _linear(layer, x, relu=False, out=None, bf16=False):
-    """nn.Linear (+ReLU) on the HIP kernels; with bf16=True a bf16 copy of the weight (kept on the layer, refreshed
-    when the weight changes) lets large batches run on the bf16 matrix-core kernel."""
+def _bf16_weight(layer):
+    """bf16 copy of an nn.Linear's weight, kept on the layer and refreshed when the weight changes."""
     W = layer.weight.detach()
-    Wb = None
-    if bf16 and W.is_cuda and x.shape[0] >= ops.LINEAR_BF16_MIN_ROWS:
-        key = (W.data_ptr(), W._version)
-        if getattr(layer, "_dvq_bf16_key", None) != key:
-            layer._dvq_bf16 = ops.to_bf16(W)
-            layer._dvq_bf16_key = key
-        Wb = layer._dvq_bf16
+    key = (W.data_ptr(), W._version)
+    if getattr(layer, "_dvq_bf16_key", None) != key:
+        layer._dvq_bf16 = ops.to_bf16(W)
+        layer._dvq_bf16_key = key
+    return layer._dvq_bf16
+
+
+def _linear(layer, x, relu=False, out=None, bf16=False):
+    """nn.Linear (+ReLU) on the HIP kernels; with bf16=True large batches run on the bf16 matrix-core kernel."""
+    W = layer.weight.detach()
+    Wb = _bf16_weight(layer) if (bf16 and W.is_cuda and x.shape[0] >= ops.LINEAR_BF16_MIN_ROWS) else None
     return ops.linear(x, W, layer.bias.detach(), relu=relu, out=out, W_bf16=Wb)
 
 
@@ -96,7 +100,59 @@ class DVQVAE(nn.Module):
         self.rh_mano = Rh_mano
         Rh_mano.eval()
 
+    def _part_tables(self, device):
+        """The six vertex lists back to back (int32) and their offsets, on `device`."""
+        cached = getattr(self, "_part_tab", None)
+        if cached is None or cached[0] != device:
+            sizes = [len(p) for p in HAND_PARTS]
+            flat = torch.tensor([v for p in HAND_PARTS for v in p], dtype=torch.int32, device=device)
+            ptr = torch.tensor([0] + [sum(sizes[:k + 1]) for k in range(len(sizes))], dtype=torch.int32, device=device)
+            self._part_tab = cached = (device, flat, ptr, sizes)
+        return cached[1:]
+
     def forward(self, obj_pc, hand_xyz):
+        """The six hand parts go through every stage together: one launch for the (centred) vertex subsets, one per
+        PointNet stage for the six part encoders and their six transform nets, one per fully connected layer for the
+        six heads, one for the six codebook searches (DVQVAE.py:42-98, 130-142)."""
+        if self.training:
+            raise RuntimeError("DVQVAE: only the inference branch is implemented; call model.eval()")
+        encs, heads = self.hand_encoders, self.handembnns
+        dt = encs[0].compute_dtype
+        if hand_xyz.dim() != 3 or hand_xyz.shape[1] != 3:
+            raise RuntimeError(f"DVQVAE: hand_xyz must be [B, 3, V], got {tuple(hand_xyz.shape)}")
+        if any(e.compute_dtype != dt for e in encs) or any(h.compute_dtype != dt for h in heads) or not hand_xyz.is_cuda:
+            return self.forward_per_part(obj_pc, hand_xyz)
+        code = DVQ_BF16 if dt == torch.bfloat16 else DVQ_F32
+        bf16 = dt == torch.bfloat16
+        obj_feat_type, _, _ = self.obj_encoder_type(obj_pc)
+        hand = hand_xyz.detach().to(torch.float32).contiguous()
+        flat, ptr, sizes = self._part_tables(hand.device)
+        parts = ops.gather_parts(hand, flat, ptr, sizes, center=True)            # centre, then hand_xyz[:, :, idx]
+        for e in encs:
+            e.stn.compute_dtype = dt
+        stn = [e.stn._packed() for e in encs]                                     # (trunk, (w4, b4, w4h), (w5, b5, w5h))
+        g = ops.pointnet_mlp_max_grouped([(parts[k], None, stn[k][0].as_dict(), True) for k in range(6)], code)
+        g = ops.linear_batched(g, [p[1][0] for p in stn], [p[1][1] for p in stn], relu=True, Ws_bf16=[p[1][2] for p in stn])
+        g = ops.linear_batched(g, [p[2][0] for p in stn], [p[2][1] for p in stn], relu=True, Ws_bf16=[p[2][2] for p in stn])
+        trans = ops.linear_batched(g, [e.stn.fc3.weight.detach() for e in encs], [e.stn.fc3.bias.detach() for e in encs],
+                                   add_identity3=True)
+        feats = ops.pointnet_mlp_max_grouped([(parts[k], trans[k], encs[k]._packed().as_dict(), False) for k in range(6)], code)
+        x = feats
+        n_mlp = len([m for m in heads[0].MLP if isinstance(m, nn.Linear)])
+        for i in range(n_mlp):
+            layers = [[m for m in h.MLP if isinstance(m, nn.Linear)][i] for h in heads]
+            x = ops.linear_batched(x, [l.weight.detach() for l in layers], [l.bias.detach() for l in layers], relu=True,
+                                   Ws_bf16=[_bf16_weight(l) for l in layers] if bf16 else None)
+        layers = [h.linear_means for h in heads]
+        lat = ops.linear_batched(x, [l.weight.detach() for l in layers], [l.bias.detach() for l in layers],
+                                 Ws_bf16=[_bf16_weight(l) for l in layers] if bf16 else None)
+        vqs = [getattr(self, f"vqvae{k}").vector_quantization for k in range(6)]
+        idxs = ops.vq_argmin_batched(lat, [v.embedding.weight.detach() for v in vqs], [v._prepared() for v in vqs])
+        idx6, obj_emb = self.vqvae6.inference(obj_feat_type)
+        return torch.cat([idx6] + [i.unsqueeze(1) for i in idxs], 0), obj_emb
+
+    def forward_per_part(self, obj_pc, hand_xyz):
+        """The same computation with one launch per part and stage (the six parts one after the other)."""
         if self.training:
             raise RuntimeError("DVQVAE: only the inference branch is implemented; call model.eval()")
         hand_xyz = hand_xyz.detach()

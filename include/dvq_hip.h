@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 104   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 105   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -63,6 +63,12 @@ int dvq_vq_argmin(const void* z, const void* E, int64_t n, int K, int D, int dty
                   int64_t* idx_out, void* zq_out, void* workspace, void* stream);
 int dvq_vq_argmin_prepared(const void* z, const void* E, int64_t n, int K, int D, int dtype,
                            int64_t* idx_out, void* zq_out, const void* workspace, void* stream);
+
+/* Up to 8 searches of ONE shape (n, K, D, dtype), each with its own latents, codebook and prepared workspace, as one
+ * launch: the six part codebooks of DVQVAE.forward (DVQ-VAE/network/DVQVAE.py:130-136, vqvae0..5.inference).  z, E,
+ * idx_out, workspace: host arrays of n_batch device pointers.  Indices only (no z_q). */
+int dvq_vq_argmin_prepared_batched(int n_batch, const void* const* z, const void* const* E, int64_t n, int K, int D,
+                                   int dtype, int64_t* const* idx_out, const void* const* workspace, void* stream);
 
 /* Replaces VectorQuantizer.get_emb (quantizer.py:68-75), batched: out[b] = E[idx[b]].
  * idx: int64 [n]; E, out: float.  `ld_out` is the row stride of `out` in elements
@@ -97,11 +103,37 @@ int dvq_pointnet_pack_w3(const float* a3 /* [1024,128] */, int dtype, void* w3p,
 int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, int C, int N,
                          const DvqPointMlp* w, int relu3, int dtype, float* feat_out, void* stream);
 
+/* Up to 8 independent dvq_pointnet_mlp_max calls (own clouds, point count, transform and weights each; one C and
+ * dtype for all) as ONE launch: the six hand-part encoders of DVQVAE.forward (DVQ-VAE/network/DVQVAE.py:20-22,
+ * 88-96 -- `hand_encoder(hand_xyz[:, :, idx])` for six vertex sets) and their six transform nets. */
+typedef struct {
+    const float* x;        /* [B, C, N] */
+    const float* trans;    /* [B, 3, 3] or NULL */
+    int B, N;
+    DvqPointMlp w;
+    int relu3;
+    float* feat_out;       /* [B, 1024] */
+} DvqPointGroup;
+/* The vertex subsets the part encoders read (DVQ-VAE/network/DVQVAE.py:49-51, 90-95: centre the hand, then
+ * `hand_xyz[:, :, idx]` for six index lists) in one launch.  pts [B,3,V]; idx: the lists back to back (device,
+ * values in [0,V), NOT checked); part_ptr [n_parts+1]: offsets into idx (device); out: part k is a contiguous
+ * [B,3,n_k] block starting at float offset 3*B*part_ptr[k].  center != 0 subtracts the per-axis mean over all V. */
+int dvq_gather_parts(const float* pts, int B, int V, const int* idx, const int* part_ptr, int n_parts, int center,
+                     float* out, void* stream);
+int dvq_pointnet_mlp_max_grouped(const DvqPointGroup* groups, int n_groups, int C, int dtype, void* stream);
+
 /* The same product with bf16 matrix-core operands and fp32 accumulation (the throughput configuration of the
  * heads: DVQ-VAE/network/DVQVAE.py:161-185, pointnet_encoder.py:35-36): x fp32 [M,K] (row stride ldx) is rounded to
  * bf16 as it is read, Wb is the weight as bf16 [N,K] row-major (dvq_to_bf16 makes it), y = act(x Wb^T + b) fp32.
  * K % 32 == 0. */
 int dvq_to_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
+/* Up to 8 products of ONE shape (own x, W, b, y each) as one launch: the six part heads of DVQVAE.forward
+ * (DVQ-VAE/network/DVQVAE.py:15-17, 97 -- `handembnn(feature)` for six parts) and the fully connected layers of the
+ * six part transform nets (pointnet_encoder.py:35-43).  x, W, b, y: host arrays of n_batch device pointers (b may be
+ * NULL); w_bf16 != 0: the W[i] are bf16 copies and the bf16 kernel runs (K % 32 == 0, no identity). */
+int dvq_linear_batched(int n_batch, const float* const* x, int64_t ldx, const void* const* W, const float* const* b,
+                       int M, int K, int N, int relu, int add_identity3, float* const* y, int64_t ldy, int w_bf16,
+                       void* stream);
 int dvq_linear_bf16(const float* x, int64_t ldx, const void* Wb, const float* b, int M, int K, int N,
                     int relu, float* y, int64_t ldy, void* stream);
 

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from dvq_hip import synth
+from dvq_hip import ops, synth
 from dvq_hip.mano_io import Struct
 from oracle import dvq_oracle as O
 from parity import rel_err
@@ -211,6 +211,55 @@ def test_dvqvae_eval_vs_reference_golden():
     assert emb_idx.shape == (14, 1) and emb_idx.dtype == torch.int64
     assert np.array_equal(emb_idx.cpu().numpy(), g["emb_idx"])
     assert np.array_equal(obj_emb.cpu().numpy(), g["obj_emb"])
+
+
+@pytest.mark.parametrize("B", [1, 5, 67, 600])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dvqvae_grouped_launches_equal_per_part_launches(B, dtype):
+    """DVQVAE.forward runs the six hand parts through every stage together (one launch per stage); the result must be
+    the one of six separate passes.  Part-level pieces are compared bit for bit: the grouped kernels run the same
+    arithmetic on the same operands.  (The hand centring sums in another order than torch.mean, so the end-to-end
+    comparison is on the indices, which the golden test above pins to the reference.)"""
+    import dvq_hip
+    from dvq_hip.hand_parts import HAND_PARTS
+    from network.DVQVAE import DVQVAE
+    model = DVQVAE(obj_inchannel=4)
+    model.load_state_dict(synth.dvqvae_state_dict(0))
+    model = model.to(DEV).eval()
+    dvq_hip.set_compute_dtype(model, dtype)
+    objs = synth.object_clouds(B, 256, seed=3).to(DEV)
+    hand = (0.05 * torch.randn(B, 3, 778, generator=torch.Generator().manual_seed(B)) + 0.3).to(DEV)
+    a_idx, a_emb = model(objs, hand)
+    b_idx, b_emb = model.forward_per_part(objs, hand)
+    assert a_idx.shape == (7 * B, 1) and torch.equal(a_emb, b_emb)
+    assert (a_idx == b_idx).float().mean().item() >= 0.999          # centring order: a latent may cross a near-tie
+    # pieces, bit for bit
+    centred = hand - hand.mean(dim=2, keepdim=True)
+    flat, ptr, sizes = model._part_tables(hand.device)
+    parts = ops.gather_parts(hand, flat, ptr, sizes, center=False)
+    for k in range(6):
+        assert torch.equal(parts[k], hand[:, :, HAND_PARTS[k]])
+    parts = ops.gather_parts(hand, flat, ptr, sizes, center=True)
+    for k in range(6):
+        assert (parts[k] - centred[:, :, HAND_PARTS[k]]).abs().max().item() <= 1e-6
+    code = dvq_hip._lib.DVQ_BF16 if dtype == torch.bfloat16 else dvq_hip._lib.DVQ_F32
+    encs = model.hand_encoders
+    groups = [(parts[k], None, encs[k].stn._packed()[0].as_dict(), True) for k in range(6)]
+    feats = ops.pointnet_mlp_max_grouped(groups, code)
+    for k in range(6):
+        assert torch.equal(feats[k], ops.pointnet_mlp_max(*groups[k], code))
+    Ws = [e.stn._packed()[1][0] for e in encs]
+    bs = [e.stn._packed()[1][1] for e in encs]
+    Wh = [e.stn._packed()[1][2] for e in encs]
+    ys = ops.linear_batched(feats, Ws, bs, relu=True, Ws_bf16=Wh)
+    for k in range(6):
+        assert torch.equal(ys[k], ops.linear(feats[k], Ws[k], bs[k], relu=True, W_bf16=Wh[k]))
+    vqs = [getattr(model, f"vqvae{k}").vector_quantization for k in range(6)]
+    lat = [torch.randn(B, 256, device=DEV, generator=torch.Generator(DEV).manual_seed(k)) * 0.01 for k in range(6)]
+    got = ops.vq_argmin_batched(lat, [v.embedding.weight.detach() for v in vqs], [v._prepared() for v in vqs])
+    for k in range(6):
+        want, _ = ops.vq_argmin(lat[k], vqs[k].embedding.weight.detach(), want_zq=False, prepared=vqs[k]._prepared())
+        assert torch.equal(got[k], want)
 
 
 def test_training_mode_and_cpu_are_refused():
