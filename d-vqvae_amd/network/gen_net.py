@@ -16,7 +16,7 @@ import torch.nn as nn
 from dvq_hip import ops
 from network.DVQVAE import Decoder, Encoder  # noqa: F401  (re-exported like the reference)
 from network.pixelcnn.models import GatedPixelCNN
-from network.pointnet_encoder import PointNetEncoder
+from network.pointnet_encoder import PointNetEncoder, encode_together
 from network.VQVAE import VQVAE
 
 # grid cells of the prior sample that hold part indices 0..5 (gen_net.py:95-100)
@@ -69,7 +69,13 @@ class GenNet(nn.Module):
         if self.rh_mano is None:
             raise RuntimeError("GenNet.gen: call set_rh_mano(mano_layer) first")
         B = obj.size()[0]
-        obj_feat_type, _, _ = self.obj_encoder_type(obj)
+        together = B < 64 and obj.is_cuda
+        if together:
+            # small batches: both object encoders stage by stage in grouped launches (each launch alone would leave
+            # most of the GPU idle)
+            (obj_feat_type, _, _), (obj_feat_pos, _, _) = encode_together([self.obj_encoder_type, self.obj_encoder_pos], obj)
+        else:
+            obj_feat_type, _, _ = self.obj_encoder_type(obj)
         idx6, _obj_emb = self.vqvae6.inference(obj_feat_type)
         # The position encoder does not depend on the prior.  The prior is a long chain of small
         # dependent launches that leaves matrix cores idle, so the second object encoder runs beside
@@ -81,7 +87,7 @@ class GenNet(nn.Module):
             with torch.cuda.stream(side):
                 obj_feat_pos, _, _ = self.obj_encoder_pos(obj)
             obj_feat_pos.record_stream(main)
-        else:
+        elif not together:
             obj_feat_pos, _, _ = self.obj_encoder_pos(obj)
         if x_tilde is None:
             label = idx6[:, 0]

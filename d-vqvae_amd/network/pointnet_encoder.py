@@ -167,3 +167,26 @@ class PointNetEncoder(nn.Module):
         # xyz @ trans, conv/bn/relu x2, conv/bn, max over points (pointnet_encoder.py:146-164)
         feat = ops.pointnet_mlp_max(x, trans.contiguous(), self._packed().as_dict(), False, _dtype_code(self.compute_dtype))
         return feat, trans, None
+
+
+def encode_together(encoders, x):
+    """Several PointNetEncoders of one configuration applied to the SAME input, every stage as one grouped launch
+    (transform-net trunks, their three fully connected layers, encoder trunks).  Same results as calling them one after
+    the other; worth it for small batches, where each launch on its own leaves most of the GPU idle.
+    Returns [(feat, trans, None), ...]."""
+    e0 = encoders[0]
+    if any(e.feature_transform or not e.global_feat or e.channel != e0.channel or e.compute_dtype != e0.compute_dtype
+           for e in encoders):
+        raise RuntimeError("encode_together: encoders must share channel count, compute dtype and the global-feature path")
+    for e in encoders:
+        x = _check_input(e, x, e.channel)
+        e.stn.compute_dtype = e.compute_dtype
+    code = _dtype_code(e0.compute_dtype)
+    stn = [e.stn._packed() for e in encoders]                      # (trunk, (w4, b4, w4h), (w5, b5, w5h))
+    g = ops.pointnet_mlp_max_grouped([(x, None, p[0].as_dict(), True) for p in stn], code)
+    g = ops.linear_batched(g, [p[1][0] for p in stn], [p[1][1] for p in stn], relu=True, Ws_bf16=[p[1][2] for p in stn])
+    g = ops.linear_batched(g, [p[2][0] for p in stn], [p[2][1] for p in stn], relu=True, Ws_bf16=[p[2][2] for p in stn])
+    trans = ops.linear_batched(g, [e.stn.fc3.weight.detach() for e in encoders], [e.stn.fc3.bias.detach() for e in encoders],
+                               add_identity3=True)
+    feats = ops.pointnet_mlp_max_grouped([(x, t, e._packed().as_dict(), False) for e, t in zip(encoders, trans)], code)
+    return [(f, t.view(-1, 3, 3), None) for f, t in zip(feats, trans)]
