@@ -164,6 +164,9 @@ def main():
                     help="also refine every generated grasp with this many test-time-adaptation steps inside the timed step "
                          "(the reference's adaptation script uses 300); default 0 = generation only")
     ap.add_argument("--no-extras", action="store_true", help="skip the VQ microbench, the variants and the CPU baseline")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; 'gloo' rehearses the multi-rank path with several ranks on ONE GPU "
+                         "(RCCL refuses two ranks per device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,14 +174,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[device.index])
+            else:
+                dist.barrier()
 
     B, N = args.batch, args.points
     tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -204,7 +213,7 @@ def main():
     def step(prior=args.prior):
         if refiner is None:
             out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None,
-                               gather=world > 1, n_total=world * B, async_gather=True)
+                               gather=world > 1, n_total=world * B, async_gather=not os.environ.get('DVQ_SYNC_GATHER'))
             finish_gathers()                       # the previous step's
             in_flight.extend(out.get("pending", []))
             return out["vertices"]
@@ -284,7 +293,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

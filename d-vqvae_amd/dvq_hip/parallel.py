@@ -37,6 +37,10 @@ def gather_rows(t: torch.Tensor, n_total: int = None, async_op: bool = False):
         out = t if n_total is None else t[:n_total]
         return (out, None) if async_op else out
     t = t.contiguous()
+    if t.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal configuration (several ranks on one GPU): gloo's staging of device tensors was seen to hang when the
+        # collective is issued behind work still running on the stream, and not when the device is idle
+        torch.cuda.synchronize(t.device)
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     work = dist.all_gather_into_tensor(out, t, async_op=async_op)
     out = out if n_total is None else out[:n_total]
