@@ -116,9 +116,26 @@ def cpu_baseline(with_prior, budget_s=12.0, batch=16):
             el = time.perf_counter() - t0
             if el >= budget_s or el + el / (done / batch) > 30.0:
                 break
+        # the reference's literal call pattern: one object per gen() call (a few seconds' worth)
+        n1, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 4.0:
+            O.generate_grasps(sd, objs[n1 % batch:n1 % batch + 1], x_tilde=None if forced is None else forced[n1 % batch:n1 % batch + 1],
+                              generator=gen)
+            n1 += 1
+        el1 = time.perf_counter() - t1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": round(done / el, 3), "unit": "grasps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model, "value_one_object_per_call": round(n1 / el1, 3),
             "sample": f"{done} grasps in batches of {batch} x 3000-pt clouds, fp32 torch CPU ops, "
-                      f"prior {'sampled' if with_prior else 'teacher-forced'}, {el:.1f} s"}
+                      f"prior {'sampled' if with_prior else 'teacher-forced'}, {el:.1f} s; then {n1} single-object calls, {el1:.1f} s"}
 
 
 def tta_bench(gen, obj, first_id, device, iters=30):
