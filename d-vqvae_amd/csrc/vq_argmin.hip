@@ -22,6 +22,13 @@
 //   |E|^2  fp32 [Kpad]; padding codes get +inf and can never win.
 #include "common.h"
 
+#include <mutex>
+
+// Workspace of dvq_vq_argmin_static: the packed codebook and |E|^2 of one search at a time.  One copy per GPU, at
+// its own address on each, held until the process ends.  In host code this name is only a handle for
+// hipGetSymbolAddress -- never a device address -- see vq_static_scratch().
+static __device__ __align__(256) unsigned char scratch[DVQ_VQ_STATIC_WORKSPACE_BYTES];
+
 namespace dvq {
 
 template <int DT> struct VqTraits;
@@ -1027,6 +1034,27 @@ static int vq_gather_impl(const int64_t* idx, const void* E, int64_t n, int K, i
     return check_launch("vq_gather");
 }
 
+// Device address of `scratch` on the current device, looked up once per device.
+constexpr int kVqMaxDevices = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[kVqMaxDevices];
+
+static int vq_static_scratch(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kVqMaxDevices)
+        return fail(DVQ_ENODEV, "vq_argmin_static: no current HIP device (or device ordinal >= %d)", kVqMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(DVQ_ELAUNCH, "vq_argmin_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return DVQ_OK;
+}
+
 }  // namespace dvq
 
 using namespace dvq;
@@ -1093,6 +1121,22 @@ extern "C" int dvq_vq_argmin(const void* z, const void* E, int64_t n, int K, int
     rc = vq_prepare_impl(E, K, D, dtype, workspace, p, as_stream(stream));
     if (rc) return rc;
     return dvq_vq_argmin_prepared(z, E, n, K, D, dtype, idx_out, zq_out, workspace, stream);
+}
+
+extern "C" int dvq_vq_argmin_static(const void* z, const void* E, int64_t n, int K, int D, int dtype, int64_t* idx_out,
+                                    void* zq_out, void* stream) {
+    VqPlan p;
+    if (!vq_plan(K, D, dtype, &p))
+        return fail(DVQ_EINVAL, "vq: unsupported shape K=%d D=%d dtype=%d (need 1<=K<=65536, 16<=D<=4096, D%%16==0)", K, D, dtype);
+    if (p.total > (size_t)DVQ_VQ_STATIC_WORKSPACE_BYTES)
+        return fail(DVQ_EINVAL, "vq_argmin_static: codebook K=%d D=%d dtype=%d needs a workspace of %zu bytes, the built-in one "
+                    "holds %zu; use dvq_vq_argmin with a caller-owned workspace", K, D, dtype, p.total,
+                    (size_t)DVQ_VQ_STATIC_WORKSPACE_BYTES);
+    void* ws = nullptr;
+    if (int rc = vq_static_scratch(&ws)) return rc;
+    // every byte the search reads (packed tiles incl. padding codes, |E|^2 of all Kpad codes) is rewritten by the
+    // prepare step below, so nothing of the previous call's contents has to be cleared
+    return dvq_vq_argmin(z, E, n, K, D, dtype, idx_out, zq_out, ws, stream);
 }
 
 extern "C" int dvq_vq_gather(const int64_t* idx, const float* E, int64_t n, int K, int D, float* out, int64_t ld_out, void* stream) {

@@ -62,6 +62,7 @@ SIGNATURES = {
     "dvq_vq_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvq_vq_argmin": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvq_vq_argmin_prepared": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dvq_vq_argmin_static": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dvq_vq_argmin_prepared_batched": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_int64, c_int, c_int, c_int,
                                                POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     "dvq_vq_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),

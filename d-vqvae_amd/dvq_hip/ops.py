@@ -112,6 +112,22 @@ def vq_argmin(z: torch.Tensor, E: torch.Tensor, want_zq: bool = True,
     return idx, zq
 
 
+def vq_argmin_static(z: torch.Tensor, E: torch.Tensor, idx: torch.Tensor, zq: Optional[torch.Tensor] = None) -> None:
+    """vq_argmin into caller-provided outputs (idx int64 [n], zq [n,D] or None) with the library's built-in
+    workspace: no device memory is allocated by this call or below it.  Raises for codebooks beyond the built-in
+    workspace.  Calls that overlap on one GPU share that workspace and race."""
+    _need_gpu(z, E, idx, zq)
+    n, D = z.shape
+    K = E.shape[0]
+    if z.dtype != E.dtype or E.shape[1] != D or idx.dtype != torch.int64 or idx.numel() != n:
+        raise RuntimeError("vq_argmin_static: z [n,D] and E [K,D] of one dtype, idx int64 [n] expected")
+    if zq is not None and (zq.dtype != z.dtype or tuple(zq.shape) != (n, D)):
+        raise RuntimeError("vq_argmin_static: zq must match z")
+    with torch.cuda.device(z.device):
+        rc = _lib.load().dvq_vq_argmin_static(_p(z), _p(E), n, K, D, _dtype_code(z), _p(idx), _p(zq), _stream(z))
+    _lib.check(rc, "dvq_vq_argmin_static")
+
+
 def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 

@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 105   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 106   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -63,6 +63,16 @@ int dvq_vq_argmin(const void* z, const void* E, int64_t n, int K, int D, int dty
                   int64_t* idx_out, void* zq_out, void* workspace, void* stream);
 int dvq_vq_argmin_prepared(const void* z, const void* E, int64_t n, int K, int D, int dtype,
                            int64_t* idx_out, void* zq_out, const void* workspace, void* stream);
+
+/* dvq_vq_argmin without the workspace argument, for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The workspace is
+ * a DVQ_VQ_STATIC_WORKSPACE_BYTES array inside the library, one copy per GPU, held until the process ends; the call
+ * allocates and frees nothing.  Codebooks with dvq_vq_workspace_bytes(K, D, dtype) above that size are rejected with
+ * DVQ_EINVAL (K=8192 x D=256 fits in both dtypes).  Same results as dvq_vq_argmin.  All calls on one GPU share the
+ * array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe. */
+#define DVQ_VQ_STATIC_WORKSPACE_BYTES (9u << 20)
+int dvq_vq_argmin_static(const void* z, const void* E, int64_t n, int K, int D, int dtype,
+                         int64_t* idx_out, void* zq_out, void* stream);
 
 /* Up to 8 searches of ONE shape (n, K, D, dtype), each with its own latents, codebook and prepared workspace, as one
  * launch: the six part codebooks of DVQVAE.forward (DVQ-VAE/network/DVQVAE.py:130-136, vqvae0..5.inference).  z, E,
