@@ -219,20 +219,14 @@ def main():
         refiner = GraspRefiner(gen.rh_mano, iters=args.tta_iters)
 
     # The all-gather of a step's vertices runs beside the next step's kernels: one step's collective is in
-    # flight at a time, and finish_gathers() completes the last one before the clock stops.
-    in_flight = []
-
-    def finish_gathers():
-        for w in in_flight:
-            w.wait()
-        in_flight.clear()
+    # flight at a time (GraspGenerator completes the previous step's), and finish_gathers() completes the last one
+    # before the clock stops.
+    finish_gathers = gen.finish
 
     def step(prior=args.prior):
         if refiner is None:
             out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None,
                                gather=world > 1, n_total=world * B, async_gather=not os.environ.get('DVQ_SYNC_GATHER'))
-            finish_gathers()                       # the previous step's
-            in_flight.extend(out.get("pending", []))
             return out["vertices"]
         # generation, then the adaptation loop on this rank's grasps, then the final hand and the gather
         out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None)
@@ -263,7 +257,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "end-to-end GenNet.gen (2 object encoders -> VQ -> prior -> decoder -> MANO -> hand "
                                    "encoder -> pos decoder) + call-site MANO LBS" +
-                                   (" + RCCL all-gather of vertices" if world > 1 else ""),
+                                   (f" + {'RCCL' if args.backend == 'nccl' else args.backend} all-gather of vertices" if world > 1 else ""),
                        "objects_per_gpu": B, "points_per_object": N, "global_batch": world * B,
                        "prior": args.prior, "tta_iterations": args.tta_iters, "weights": "random-init (seed 0), MANO-shaped synthetic hand model",
                        "parallelism": f"dp{world}"},

@@ -29,8 +29,15 @@ class GraspGenerator:
         self.model = model
         self.rh_mano = rh_mano
         self.seed = seed
+        self._in_flight = []          # work handles of asynchronous gathers, one list per generate() call
         if model.rh_mano is None:
             model.set_rh_mano(rh_mano)
+
+    def finish(self, keep_newest: bool = False):
+        """Complete the asynchronous gathers issued so far (all but the newest call's with keep_newest)."""
+        while len(self._in_flight) > (1 if keep_newest else 0):
+            for w in self._in_flight.pop(0):
+                w.wait()
 
     @classmethod
     def synthetic(cls, device, seed: int = 0, dtype=torch.float32, with_prior: bool = True):
@@ -52,23 +59,36 @@ class GraspGenerator:
         """obj [B,4,N] (this rank's shard; object b has global id first_id+b).
         Returns dict(recon_param [B,61], vertices [B,778,3]); with gather=True the vertices
         (and parameters) of all ranks, in global object order.  With async_gather=True the two
-        all-gathers are left running beside whatever the caller launches next: the dict then carries
-        "pending", the work handles to wait() on before the gathered tensors are read."""
+        all-gathers are left running beside whatever the caller launches next -- one call's gathers are in flight
+        at a time, the previous call's are completed before this one returns -- and finish() completes the last;
+        the dict also carries "pending", this call's work handles.
+        Objects are dealt to ranks by parallel.shard_range(n_total, rank, world); a rank whose shard is empty
+        (B = 0) launches nothing and still takes part in the collective."""
         B = obj.shape[0]
-        if x_tilde is None:
+        prior = getattr(self.model, "GatedPixelCNN", None)
+        if self._in_flight and x_tilde is None and prior is not None and not prior.graph_ready(B):
+            self.finish()            # the prior is about to record a HIP graph: no collective may be pending then
+        if B == 0:
+            param = torch.zeros((0, 61), dtype=torch.float32, device=obj.device)
+            verts = torch.zeros((0, 778, 3), dtype=torch.float32, device=obj.device)
+        elif x_tilde is None:
             ids = torch.arange(first_id, first_id + B, device=obj.device)
             u = rng.uniforms(ids, 9, self.seed)
             recon, pos = self.model.gen(obj, uniforms=u)
         else:
             recon, pos = self.model.gen(obj, x_tilde=x_tilde)
-        param = assemble_param(recon, pos)
-        out = self.rh_mano(betas=param[:, :10], global_orient=param[:, 10:13].contiguous(),
-                           hand_pose=param[:, 13:58].contiguous(), transl=param[:, 58:].contiguous())
-        verts = out.vertices
+        if B > 0:
+            param = assemble_param(recon, pos)
+            out = self.rh_mano(betas=param[:, :10], global_orient=param[:, 10:13].contiguous(),
+                               hand_pose=param[:, 13:58].contiguous(), transl=param[:, 58:].contiguous())
+            verts = out.vertices
         if gather and async_gather:
             verts, wv = parallel.gather_rows(verts, n_total, async_op=True)
             param, wp = parallel.gather_rows(param, n_total, async_op=True)
-            return dict(recon_param=param, vertices=verts, pending=[w for w in (wv, wp) if w is not None])
+            pending = [w for w in (wv, wp) if w is not None]
+            self._in_flight.append(pending)
+            self.finish(keep_newest=True)
+            return dict(recon_param=param, vertices=verts, pending=pending)
         if gather:
             verts = parallel.gather_rows(verts, n_total)
             param = parallel.gather_rows(param, n_total)

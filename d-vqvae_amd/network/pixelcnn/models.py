@@ -181,6 +181,20 @@ class GatedPixelCNN(nn.Module):
             self._bufs = {}
         return self._packed
 
+    def graph_ready(self, batch_size, shape=(3, 3)):
+        """False when the next generate(..., uniforms=u) of this batch size will record a HIP graph (first call of a
+        batch size, or weights changed since): callers with asynchronous work of their own in flight (a pending
+        collective) complete it first.  True when a recorded graph will be replayed or none is used."""
+        if not self.use_graph or not self.embedding.weight.is_cuda:
+            return True
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        dev = str(self.embedding.weight.device)
+        if self.compute_dtype == torch.bfloat16:
+            b = self._bufs.get((batch_size, shape[0], shape[1], dev))
+            return key == self._packed_key and b is not None and b.get("graph") is not None
+        st = self._bufs32.get(("f32", batch_size, shape[0], shape[1], dev))
+        return st is not None and getattr(self, "_bufs32_key", None) == (key, self.compute_dtype)
+
     def _act_buffers(self, B, H, W, dev):
         """Packed activation buffers for a batch of B grids, allocated once per (B, H, W)."""
         key = (B, H, W, str(dev))
