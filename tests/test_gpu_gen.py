@@ -97,9 +97,9 @@ def test_prior_incremental_sampling_equals_full_forwards():
 
 
 def test_prior_bf16_kernels_vs_fp32():
-    """The fused bf16 prior kernels against the fp32 evaluation on the same forced grid.
-    Stated tolerance: per-cell class probabilities within 5e-2 absolute (bf16 operands through
-    15 gated layers), and >= 85 % of the sampled indices equal for identical uniforms."""
+    """The fused bf16 prior kernels against the CPU oracle and the fp32 evaluation on the same forced grid.
+    Stated tolerance: per-cell class probabilities within 5e-3 absolute (bf16 operands through
+    15 gated layers), and >= 92 % of the sampled indices equal for identical uniforms."""
     model, _ = build()
     prior = model.GatedPixelCNN
     B = 100                                    # not a multiple of the 32-row tile
@@ -115,8 +115,11 @@ def test_prior_bf16_kernels_vs_fp32():
     ref = prior.generate_full(lab, shape=(3, 3), batch_size=B, forced=x16)
     err = (p16 - ref).abs().max().item()
     agree = (x16 == x32).float().mean().item()
-    print(f"bf16 prior: max |dp| {err:.3e}, sampled-index agreement {agree:.3f}")
-    assert err <= 5e-2 and agree >= 0.85 and int(x16.max()) < 128
+    sd = synth.gennet_state_dict(0, with_prior=True)
+    _, p_cpu = O.pixelcnn_generate(sd, lab[:8].cpu(), (3, 3), forced=x16[:8].cpu())    # the reference's nine full forwards
+    err_oracle = (p16[:8].cpu().view(8, 3, 3, -1) - p_cpu).abs().max().item()
+    print(f"bf16 prior: max |dp| {err:.3e} vs fp32, {err_oracle:.3e} vs oracle; sampled-index agreement {agree:.3f}")
+    assert err <= 5e-3 and err_oracle <= 5e-3 and agree >= 0.92 and int(x16.max()) < 128
     prior.compute_dtype = torch.bfloat16
     x16b = prior.generate(None, lab[32:77].contiguous(), shape=(3, 3), batch_size=45, uniforms=u[32:77].contiguous())
     assert torch.equal(x16b, x16[32:77])       # independent of batch composition
@@ -183,7 +186,7 @@ def test_prior_sample_kernel_equals_softmax_cumsum_searchsorted():
 
 def test_gen_bf16_stated_tolerance():
     """bf16 encoders: vertices within 2 mm of the fp32 path on a ~0.2 m hand (stated
-    tolerance), object-code agreement reported."""
+    tolerance), object codes equal for >= 90 % of the objects (measured: all 32)."""
     import dvq_hip
     model, rh = build(with_prior=False)
     objs = synth.object_clouds(32, 3000, seed=77).to(DEV)
@@ -197,7 +200,7 @@ def test_gen_bf16_stated_tolerance():
     agree = (model.last_idx6 == idx32).float().mean().item()
     err = (v16 - v32).abs().max().item()
     print(f"bf16 vs fp32: max vertex deviation {err * 1000:.3f} mm, object-code agreement {agree:.3f}")
-    assert err <= 2e-3
+    assert err <= 2e-3 and agree >= 0.9
 
 
 def test_dvqvae_eval_vs_reference_golden():
