@@ -31,6 +31,20 @@ def test_mano_vs_reference_golden():
     assert rel_err(out.full_pose, g["full_pose"]) <= 1e-6
 
 
+def test_mano_vs_reference_golden_on_real_grasp_parameters():
+    """The reference MANO class on the 120 parameter vectors its trained model produced (DVQ-VAE-2's stored HMDO
+    outputs; PCA coefficients up to +-7.6) + rest pose + large angles: joints of every row, vertices of every second."""
+    g = load_golden("mano_hmdo")
+    p = torch.from_numpy(g["recon_params"]).to(DEV)
+    rh = make_mano(1)
+    out = rh(betas=p[:, :10].contiguous(), global_orient=p[:, 10:13].contiguous(), hand_pose=p[:, 13:58].contiguous(),
+             transl=p[:, 58:].contiguous())
+    ev = rel_err(out.vertices[::2], g["vertices_even"])
+    ej = rel_err(out.joints, g["joints"])
+    print(f"MANO on real grasp parameters: vertices {ev:.2e}, joints {ej:.2e} (relative to max |.|)")
+    assert ev <= 1e-5 and ej <= 1e-5
+
+
 @pytest.mark.parametrize("B", [1, 3, 8, 9, 67])
 def test_mano_batches_vs_oracle(B):
     rh = make_mano(1)
@@ -130,7 +144,7 @@ def test_pointnet_f32_vs_reference_golden():
     enc = _encoder("obj_encoder_type.", 4)
     x4 = torch.cat([torch.from_numpy(g["real_clouds"]), synth.object_clouds(4, 3000, seed=7)], 0)
     feat, trans, tf = enc(x4.to(DEV))
-    assert tf is None and feat.shape == (6, 1024) and trans.shape == (6, 3, 3)
+    assert tf is None and feat.shape == (8, 1024) and trans.shape == (8, 3, 3)
     assert rel_err(trans, g["trans4"]) <= 1e-5
     assert rel_err(feat, g["feat4"]) <= 1e-5
     enc3 = _encoder("recon_encoder.", 3)

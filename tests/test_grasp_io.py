@@ -132,3 +132,33 @@ def test_diverse_grasps_batch_equals_one_call_per_placement():
         # batch-of-6 and batch-of-1 take different matrix-product code paths (summation order): float32 noise only
         assert torch.allclose(one["vertices"][0], verts[i], rtol=0, atol=2e-6), float((one["vertices"][0] - verts[i]).abs().max())
         assert np.allclose(np.asarray(rec["recon_params"][i][0], dtype=np.float32), one["recon_param"][0].cpu().numpy(), atol=2e-5)
+
+
+def test_reader_and_placements_against_the_reference_stored_outputs():
+    """tests/golden/hmdo_obj_id_0.json is one file the reference's generation script wrote
+    (DVQ-VAE-2/diverse_grasp/HMDO/obj_id_0.json, gen_diverse_grasp_ho3d.py:322-331); mano_hmdo.npz holds the
+    placements of all twelve.  The reader must return its arrays, and every stored rotation must be the
+    Rx Ry Rz product of its stored Euler angles (gen_diverse_grasp_ho3d.py:214-222)."""
+    import os
+    from conftest import GOLDEN, load_golden
+    from dvq_hip import grasp_io
+    g = load_golden("mano_hmdo")
+    rec = grasp_io.read_grasp_json(os.path.join(GOLDEN, "hmdo_obj_id_0.json"))
+    assert rec["recon_params"].shape == (10, 61) and rec["R"].shape == (10, 3, 4)
+    assert rec["trans"].shape == (10, 3, 1) and rec["r"].shape == (10, 3)
+    np.testing.assert_array_equal(rec["recon_params"], g["recon_params"][:10])
+    np.testing.assert_array_equal(rec["R"], g["R"][:10])
+    for i in range(120):
+        np.testing.assert_allclose(grasp_io.euler_rotation(g["r"][i]), g["R"][i][:, :3], rtol=0, atol=1e-15)
+        # (the translations are not the bare constant of gen_diverse_grasp_ho3d.py:221: the script that wrote these
+        # files also subtracted an object mean, as gen_diverse_grasp_FHAB.py:210 does; only R = [rot | trans] holds)
+        np.testing.assert_array_equal(g["trans"][i][:, 0], g["R"][i][:, 3])
+    # a record written back reads the same
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "o.json")
+        grasp_io.write_grasp_json(path, grasp_io.grasp_record(torch.from_numpy(rec["recon_params"]),
+                                                              dict(R=rec["R"], trans=rec["trans"], r=rec["r"])))
+        back = grasp_io.read_grasp_json(path)
+    for k in rec:
+        np.testing.assert_array_equal(back[k], rec[k])

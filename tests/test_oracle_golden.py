@@ -69,6 +69,18 @@ def test_mano_oracle_vs_reference():
     np.testing.assert_allclose(j.numpy(), g["joints"], rtol=1e-5, atol=1e-6)
 
 
+def test_mano_oracle_vs_reference_on_real_grasp_parameters():
+    """120 parameter vectors the trained reference model produced (its stored HMDO outputs) + a rest pose and
+    two large-angle rows, through the reference MANO class."""
+    g = load_golden("mano_hmdo")
+    p = torch.from_numpy(g["recon_params"])
+    assert p.shape == (123, 61)
+    sd = synth.mano_state_dict(0, batch_size=1)
+    v, j, _ = O.mano_forward(sd, p[:, 10:13], p[:, 13:58], p[:, 58:61])
+    np.testing.assert_allclose(j.numpy(), g["joints"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(v[::2].numpy(), g["vertices_even"], rtol=1e-5, atol=2e-6)
+
+
 def test_dvqvae_eval_oracle_vs_reference():
     g = load_golden("dvqvae")
     sd = synth.dvqvae_state_dict(0)
