@@ -70,6 +70,50 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 
 enum { PG_PACK = 0, PG_GATE = 1, PG_ROWS = 2 };
 
+// The same kernels run in exact fp32 (the parity configuration; DT = DVQ_F32) on the 32x32x2 f32 MFMA: a 1-KiB unit
+// then holds 8 features instead of 16 (four floats per lane = four MFMA k-steps),
+//     unit(fb, sb, q) = 64 lanes x 4 floats:  lane (c,h), j -> feature 32fb + 8q + 4h + j of sample 32sb + c,
+// which is registers 4q .. 4q+3 of a 32x32 accumulator tile, so the accumulator is still stored as is.
+template <int DT> struct PgT;
+template <> struct PgT<DVQ_BF16> { static constexpr int UPB = 2; };   // units per block of 32 features
+template <> struct PgT<DVQ_F32> { static constexpr int UPB = 4; };
+
+__device__ __forceinline__ float pg_tanh(float x, bool exact) { return exact ? tanhf(x) : fast_tanh(x); }
+__device__ __forceinline__ float pg_sigmoid(float x, bool exact) { return exact ? 1.f / (1.f + expf(-x)) : fast_sigmoid(x); }
+
+// 32 features x 32 samples of a tile (y[16] of this lane) -> packed units at `base` (first unit of the block)
+template <int DT>
+__device__ __forceinline__ void pg_store_block(char* base, int lane, const float* y) {
+    if (DT == DVQ_BF16) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<uint4*>(base + s2 * 1024 + lane * 16) = pack8(y + 8 * s2);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o; o[0] = y[4 * q]; o[1] = y[4 * q + 1]; o[2] = y[4 * q + 2]; o[3] = y[4 * q + 3];
+            *reinterpret_cast<f32x4*>(base + q * 1024 + lane * 16) = o;
+        }
+    }
+}
+template <int DT>
+__device__ __forceinline__ void pg_add_block(const char* base, int lane, float* y) {
+    if (DT == DVQ_BF16) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const u16x8 rr = *reinterpret_cast<const u16x8*>(base + s2 * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[8 * s2 + j] += bf16_bits_to_f32(rr[j]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(base + q * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[4 * q + j] += rr[j];
+        }
+    }
+}
+
 // grid: x = output-feature group (NO tiles of 32; for GATE NO/2 + the matching NO/2 of the upper
 //       half), y = group of 4 sample tiles (one per wave), z = job.  One workgroup per CU.
 //
@@ -85,7 +129,7 @@ enum { PG_PACK = 0, PG_GATE = 1, PG_ROWS = 2 };
 // and R = 3 (48 KiB) keep two loads in flight per wave, which is enough to saturate that path, and
 // leave room in LDS for workgroups of the point-cloud encoder that runs beside the prior on another
 // stream; smaller batches are latency-bound and take KS = 2 (half as many barriers per product).
-template <int EPI, int NO, int KS>
+template <int DT, int EPI, int NO, int KS>
 __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
     // These products form a long dependent chain of short launches; when another stream's long-running kernel
     // (the point-cloud encoder) shares the CU, win the SIMD's issue arbitration so the chain keeps its pace.
@@ -93,11 +137,13 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PgJobDev& job = jobs.j[blockIdx.z];
     constexpr int NS = 1;
-    constexpr int W_UNITS = NO * KS * 2;
-    constexpr int X_UNITS = kPgWaves * KS * 2;
+    constexpr int UPB = PgT<DT>::UPB;
+    constexpr int KU = KS * UPB;                                 // units per operand tile and stage
+    constexpr int W_UNITS = NO * KU;
+    constexpr int X_UNITS = kPgWaves * KU;
     constexpr int STAGE_BYTES = (W_UNITS + X_UNITS) * 1024;
     constexpr int R = kPgRing;
-    constexpr int GLDS_PER_STAGE = W_UNITS / kPgWaves + KS * 2;  // per wave
+    constexpr int GLDS_PER_STAGE = W_UNITS / kPgWaves + KU;      // per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -140,13 +186,13 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
 #pragma unroll
         for (int i = 0; i < W_UNITS / kPgWaves; ++i) {
             const int u = wave + kPgWaves * i;
-            const int t = u / (KS * 2), q = u % (KS * 2);
-            pg_glds16(w + ((int64_t)(ob[t] * KB + kb0) * 2 + q) * 1024 + lane * 16, dst + u * 1024);
+            const int t = u / KU, q = u % KU;
+            pg_glds16(w + ((int64_t)(ob[t] * KB + kb0) * UPB + q) * 1024 + lane * 16, dst + u * 1024);
         }
 #pragma unroll
-        for (int q = 0; q < KS * 2; ++q)
-            pg_glds16(x + (((int64_t)(kb0 + (q >> 1)) * SB + sb[0]) * 2 + (q & 1)) * 1024 + lane * 16,
-                      dst + (W_UNITS + wave * KS * 2 + q) * 1024);
+        for (int q = 0; q < KU; ++q)
+            pg_glds16(x + (((int64_t)(kb0 + q / UPB) * SB + sb[0]) * UPB + (q % UPB)) * 1024 + lane * 16,
+                      dst + (W_UNITS + wave * KU + q) * 1024);
     };
     auto advance = [&](int& tp, int& k0) {
         k0 += KS;
@@ -173,12 +219,23 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
         }
         const char* sbuf = smem + (st % R) * STAGE_BYTES + lane * 16;
 #pragma unroll
-        for (int q = 0; q < KS * 2; ++q) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sbuf + (W_UNITS + wave * KS * 2 + q) * 1024);
+        for (int q = 0; q < KU; ++q) {
+            if constexpr (DT == DVQ_BF16) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sbuf + (W_UNITS + wave * KU + q) * 1024);
 #pragma unroll
-            for (int t = 0; t < NO; ++t) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sbuf + (t * KS * 2 + q) * 1024);
-                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t][0], 0, 0, 0);
+                for (int t = 0; t < NO; ++t) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sbuf + (t * KU + q) * 1024);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t][0], 0, 0, 0);
+                }
+            } else {
+                const f32x4 xf = *reinterpret_cast<const f32x4*>(sbuf + (W_UNITS + wave * KU + q) * 1024);
+                f32x4 wf[NO];
+#pragma unroll
+                for (int t = 0; t < NO; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sbuf + (t * KU + q) * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NO; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t][j], xf[j], acc[t][0], 0, 0, 0);
             }
         }
     }
@@ -208,16 +265,13 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
                         const int i = 4 * q4 + q;
                         pre_lo[i] = acc[t][s][i] + blo[q];
                         pre_hi[i] = acc[t + NO / 2][s][i] + bhi[q];
-                        g[i] = fast_tanh(pre_lo[i] + clo[q]) * fast_sigmoid(pre_hi[i] + chi[q]);
+                        g[i] = pg_tanh(pre_lo[i] + clo[q], DT == DVQ_F32) * pg_sigmoid(pre_hi[i] + chi[q], DT == DVQ_F32);
                     }
                 }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    *reinterpret_cast<uint4*>(job.out_packed + (((int64_t)ob[t] * SB + sb[s]) * 2 + s2) * 1024 + lane * 16) = pack8(g + 8 * s2);
-                    if (job.out_pre) {
-                        *reinterpret_cast<uint4*>(job.out_pre + (((int64_t)ob[t] * SB + sb[s]) * 2 + s2) * 1024 + lane * 16) = pack8(pre_lo + 8 * s2);
-                        *reinterpret_cast<uint4*>(job.out_pre + (((int64_t)ob[t + NO / 2] * SB + sb[s]) * 2 + s2) * 1024 + lane * 16) = pack8(pre_hi + 8 * s2);
-                    }
+                pg_store_block<DT>(job.out_packed + ((int64_t)ob[t] * SB + sb[s]) * UPB * 1024, lane, g);
+                if (job.out_pre) {
+                    pg_store_block<DT>(job.out_pre + ((int64_t)ob[t] * SB + sb[s]) * UPB * 1024, lane, pre_lo);
+                    pg_store_block<DT>(job.out_pre + ((int64_t)ob[t + NO / 2] * SB + sb[s]) * UPB * 1024, lane, pre_hi);
                 }
             }
         } else {
@@ -238,20 +292,13 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
                     }
                 }
                 if (EPI == PG_PACK) {
+                    const int64_t off = ((int64_t)ob[t] * SB + sb[s]) * UPB * 1024;
+                    if (job.resid) pg_add_block<DT>(job.resid + off, lane, y);
+                    if (relu) {
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const int64_t off = (((int64_t)ob[t] * SB + sb[s]) * 2 + s2) * 1024 + lane * 16;
-                        if (job.resid) {
-                            const u16x8 rr = *reinterpret_cast<const u16x8*>(job.resid + off);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) y[8 * s2 + j] += bf16_bits_to_f32(rr[j]);
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) y[8 * s2 + j] = y[8 * s2 + j] > 0.f ? y[8 * s2 + j] : 0.f;
-                        }
-                        *reinterpret_cast<uint4*>(job.out_packed + off) = pack8(y + 8 * s2);
+                        for (int j = 0; j < 16; ++j) y[j] = y[j] > 0.f ? y[j] : 0.f;
                     }
+                    pg_store_block<DT>(job.out_packed + off, lane, y);
                 }
             }
         }
@@ -259,47 +306,75 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
 }
 
 // W [N, K] (fp32, element (n,k) at W[n*ldn + k*ldk]) -> packed A-fragment units
-//   unit (ob, fb, s): lane (r,h), j -> W[32ob + r][32fb + 16s + 8(j>>2) + 4h + (j&3)]
+//   bf16 unit (ob, fb, s): lane (r,h), j -> W[32ob + r][32fb + 16s + 8(j>>2) + 4h + (j&3)]
+//   fp32 unit (ob, fb, q): lane (r,h), j -> W[32ob + r][32fb + 8q + 4h + j]
+template <int DT>
 __global__ void prior_pack_weight_kernel(const float* __restrict__ W, int64_t ldn, int64_t ldk, int N, int K, uint4* __restrict__ out) {
+    constexpr int UPB = PgT<DT>::UPB;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int KB = K / 32;
-    const int64_t total = (int64_t)(N / 32) * KB * 2 * 64;
+    const int64_t total = (int64_t)(N / 32) * KB * UPB * 64;
     if (t >= total) return;
     const int l = (int)(t & 63);
     const int64_t unit = t >> 6;
-    const int s = (int)(unit & 1);
-    const int fb = (int)((unit >> 1) % KB);
-    const int ob = (int)((unit >> 1) / KB);
+    const int s = (int)(unit % UPB);
+    const int fb = (int)((unit / UPB) % KB);
+    const int ob = (int)((unit / UPB) / KB);
     const int r = l & 31, h = l >> 5;
-    float v[8];
+    const float* row = W + (int64_t)(32 * ob + r) * ldn;
+    if (DT == DVQ_BF16) {
+        float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)(32 * ob + r) * ldn + (int64_t)(32 * fb + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * ldk];
-    out[t] = pack8(v);
+        for (int j = 0; j < 8; ++j) v[j] = row[(int64_t)(32 * fb + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * ldk];
+        out[t] = pack8(v);
+    } else {
+        uint4 o;
+        o.x = __builtin_bit_cast(unsigned, row[(int64_t)(32 * fb + 8 * s + 4 * h + 0) * ldk]);
+        o.y = __builtin_bit_cast(unsigned, row[(int64_t)(32 * fb + 8 * s + 4 * h + 1) * ldk]);
+        o.z = __builtin_bit_cast(unsigned, row[(int64_t)(32 * fb + 8 * s + 4 * h + 2) * ldk]);
+        o.w = __builtin_bit_cast(unsigned, row[(int64_t)(32 * fb + 8 * s + 4 * h + 3) * ldk]);
+        out[t] = o;
+    }
+}
+
+// One lane's 16 bytes of packed unit (fb, s) for a row of an fp32 table: features as in the activation layouts above.
+template <int DT>
+__device__ __forceinline__ uint4 pg_pack_row_piece(const float* src_row, int fb, int s, int h) {
+    if (DT == DVQ_BF16) {
+        const float* src = src_row + 32 * fb + 16 * s + 4 * h;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[8 * (j >> 2) + (j & 3)];
+        return pack8(v);
+    }
+    const float* src = src_row + 32 * fb + 8 * s + 4 * h;
+    uint4 o;
+    o.x = __builtin_bit_cast(unsigned, src[0]); o.y = __builtin_bit_cast(unsigned, src[1]);
+    o.z = __builtin_bit_cast(unsigned, src[2]); o.w = __builtin_bit_cast(unsigned, src[3]);
+    return o;
 }
 
 // packed[fb][sb][s][lane] <- table[idx[m]][feature]   (embedding rows of sampled indices)
+template <int DT>
 __global__ void prior_embed_kernel(const int64_t* __restrict__ idx, int64_t idx_stride, const float* __restrict__ table, int V, int M, int d,
                                    uint4* __restrict__ out) {
+    constexpr int UPB = PgT<DT>::UPB;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int SB = (M + 31) / 32;
-    const int64_t total = (int64_t)(d / 32) * SB * 2 * 64;
+    const int64_t total = (int64_t)(d / 32) * SB * UPB * 64;
     if (t >= total) return;
     const int l = (int)(t & 63);
     const int64_t unit = t >> 6;
-    const int s = (int)(unit & 1);
-    const int sbk = (int)((unit >> 1) % SB);
-    const int fb = (int)((unit >> 1) / SB);
+    const int s = (int)(unit % UPB);
+    const int sbk = (int)((unit / UPB) % SB);
+    const int fb = (int)((unit / UPB) / SB);
     const int c = l & 31, h = l >> 5;
     int m = sbk * 32 + c;
     if (m >= M) m = M - 1;
     int64_t row = idx[(int64_t)m * idx_stride];
     if (row < 0) row = 0;
     if (row >= V) row = V - 1;
-    const float* src = table + row * d + 32 * fb + 16 * s + 4 * h;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[8 * (j >> 2) + (j & 3)];
-    out[t] = pack8(v);
+    out[t] = pg_pack_row_piece<DT>(table + row * d, fb, s, h);
 }
 
 
@@ -452,6 +527,7 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int
 // the softmax does, the cumulative sum in fp64; index = number of cdf entries <= u, clamped to the last class.
 constexpr int kPsMaxPer = 16;   // classes per lane: up to 1024 classes
 
+template <int DT>
 __global__ __launch_bounds__(256) void prior_sample_kernel(const float* __restrict__ logits, int n, int M,
                                                            const double* __restrict__ u, int64_t u_stride,
                                                            int64_t* __restrict__ x_out, int64_t x_stride,
@@ -518,16 +594,13 @@ __global__ __launch_bounds__(256) void prior_sample_kernel(const float* __restri
         const int SB = (M + 31) / 32;
         const int sbk = m >> 5, cc = m & 31;
         const float* src_row = table + (int64_t)idx * d;
-        for (int piece = lane; piece < (d / 32) * 4; piece += 64) {
-            const int fb = piece >> 2, s2 = (piece >> 1) & 1, hh = piece & 1;
-            const float* src = src_row + 32 * fb + 16 * s2 + 4 * hh;
-            float e[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = src[8 * (j >> 2) + (j & 3)];
-            const uint4 pk = pack8(e);
+        constexpr int UPB = PgT<DT>::UPB;
+        for (int piece = lane; piece < (d / 32) * UPB * 2; piece += 64) {
+            const int fb = piece / (UPB * 2), s2 = (piece >> 1) % UPB, hh = piece & 1;
+            const uint4 pk = pg_pack_row_piece<DT>(src_row, fb, s2, hh);
             // the last row also fills the unused rows of its 32-row block, as prior_embed does
             const int reps = (m == M - 1) ? (SB * 32 - m) : 1;
-            for (int rr = 0; rr < reps; ++rr) emb_out[((int64_t)(fb * SB + sbk) * 2 + s2) * 64 + hh * 32 + cc + rr] = pk;
+            for (int rr = 0; rr < reps; ++rr) emb_out[((int64_t)(fb * SB + sbk) * UPB + s2) * 64 + hh * 32 + cc + rr] = pk;
         }
     }
 }
@@ -536,24 +609,34 @@ __global__ __launch_bounds__(256) void prior_sample_kernel(const float* __restri
 
 using namespace dvq;
 
-extern "C" size_t dvq_prior_packed_bytes(int rows, int features) {
-    if (rows < 1 || features < 32 || (features % 32) != 0) return 0;
-    return (size_t)(features / 32) * ((rows + 31) / 32) * 2048;
+static bool pg_dtype_ok(int dtype) { return dtype == DVQ_BF16 || dtype == DVQ_F32; }
+
+extern "C" size_t dvq_prior_packed_bytes(int rows, int features, int dtype) {
+    if (rows < 1 || features < 32 || (features % 32) != 0 || !pg_dtype_ok(dtype)) return 0;
+    return (size_t)(features / 32) * ((rows + 31) / 32) * (dtype == DVQ_F32 ? 4096 : 2048);
 }
 
-extern "C" int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K, void* out, void* stream) {
-    if (!W || !out || N < 32 || K < 32 || (N % 32) || (K % 32)) return fail(DVQ_EINVAL, "prior_pack_weight: N and K must be multiples of 32");
-    const int64_t total = (int64_t)(N / 32) * (K / 32) * 2 * 64;
-    hipLaunchKernelGGL(prior_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), W, ldn, ldk, N, K,
-                       reinterpret_cast<uint4*>(out));
+extern "C" int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K, int dtype, void* out, void* stream) {
+    if (!W || !out || N < 32 || K < 32 || (N % 32) || (K % 32) || !pg_dtype_ok(dtype))
+        return fail(DVQ_EINVAL, "prior_pack_weight: N and K must be multiples of 32, dtype DVQ_F32 or DVQ_BF16");
+    const int64_t total = (int64_t)(N / 32) * (K / 32) * (dtype == DVQ_F32 ? 4 : 2) * 64;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == DVQ_F32)
+        hipLaunchKernelGGL(prior_pack_weight_kernel<DVQ_F32>, grid, dim3(256), 0, as_stream(stream), W, ldn, ldk, N, K, reinterpret_cast<uint4*>(out));
+    else
+        hipLaunchKernelGGL(prior_pack_weight_kernel<DVQ_BF16>, grid, dim3(256), 0, as_stream(stream), W, ldn, ldk, N, K, reinterpret_cast<uint4*>(out));
     return check_launch("prior_pack_weight");
 }
 
-extern "C" int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, void* out, void* stream) {
-    if (!idx || !table || !out || M < 1 || d < 32 || (d % 32)) return fail(DVQ_EINVAL, "prior_embed: bad arguments");
-    const int64_t total = (int64_t)(d / 32) * ((M + 31) / 32) * 2 * 64;
-    hipLaunchKernelGGL(prior_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), idx, idx_stride, table, V, M, d,
-                       reinterpret_cast<uint4*>(out));
+extern "C" int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, int dtype, void* out,
+                               void* stream) {
+    if (!idx || !table || !out || M < 1 || d < 32 || (d % 32) || !pg_dtype_ok(dtype)) return fail(DVQ_EINVAL, "prior_embed: bad arguments");
+    const int64_t total = (int64_t)(d / 32) * ((M + 31) / 32) * (dtype == DVQ_F32 ? 4 : 2) * 64;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == DVQ_F32)
+        hipLaunchKernelGGL(prior_embed_kernel<DVQ_F32>, grid, dim3(256), 0, as_stream(stream), idx, idx_stride, table, V, M, d, reinterpret_cast<uint4*>(out));
+    else
+        hipLaunchKernelGGL(prior_embed_kernel<DVQ_BF16>, grid, dim3(256), 0, as_stream(stream), idx, idx_stride, table, V, M, d, reinterpret_cast<uint4*>(out));
     return check_launch("prior_embed");
 }
 
@@ -584,17 +667,23 @@ extern "C" int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream)
 }
 
 extern "C" int dvq_prior_sample(const float* logits, int n_classes, int M, const double* u, int64_t u_stride, int64_t* x_out,
-                                int64_t x_stride, const float* table, int d, void* emb_out, void* stream) {
+                                int64_t x_stride, const float* table, int d, int emb_dtype, void* emb_out, void* stream) {
     if (!logits || !u || !x_out || M < 1) return fail(DVQ_EINVAL, "prior_sample: bad arguments");
     if (n_classes < 1 || n_classes > 64 * kPsMaxPer) return fail(DVQ_EINVAL, "prior_sample: 1..%d classes (got %d)", 64 * kPsMaxPer, n_classes);
-    if (emb_out && (!table || d < 32 || (d % 32))) return fail(DVQ_EINVAL, "prior_sample: embedding width must be a multiple of 32");
-    hipLaunchKernelGGL(prior_sample_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logits, n_classes, M, u, u_stride, x_out,
-                       x_stride, table, d, reinterpret_cast<uint4*>(emb_out));
+    if (emb_out && (!table || d < 32 || (d % 32) || !pg_dtype_ok(emb_dtype)))
+        return fail(DVQ_EINVAL, "prior_sample: embedding width must be a multiple of 32, emb_dtype DVQ_F32 or DVQ_BF16");
+    if (emb_out && emb_dtype == DVQ_F32)
+        hipLaunchKernelGGL(prior_sample_kernel<DVQ_F32>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logits, n_classes, M, u, u_stride,
+                           x_out, x_stride, table, d, reinterpret_cast<uint4*>(emb_out));
+    else
+        hipLaunchKernelGGL(prior_sample_kernel<DVQ_BF16>, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logits, n_classes, M, u, u_stride,
+                           x_out, x_stride, table, d, reinterpret_cast<uint4*>(emb_out));
     return check_launch("prior_sample");
 }
 
-extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, void* stream) {
+extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, int dtype, void* stream) {
     if (!jobs || n_jobs < 1 || n_jobs > 3) return fail(DVQ_EINVAL, "prior_gemm: 1..3 jobs per launch");
+    if (!pg_dtype_ok(dtype)) return fail(DVQ_EINVAL, "prior_gemm: dtype must be DVQ_F32 or DVQ_BF16");
     if (M < 1 || N < 128 || (N % 128) != 0) return fail(DVQ_EINVAL, "prior_gemm: N must be a multiple of 128 (got %d)", N);
     if (epilogue == PG_GATE && (N % 256) != 0) return fail(DVQ_EINVAL, "prior_gemm: the gate epilogue needs N %% 256 == 0");
     PgJobs dev;
@@ -620,7 +709,9 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
         if (epilogue == PG_ROWS && !s.out_rows) return fail(DVQ_EINVAL, "prior_gemm: out_rows missing");
     }
     const int SB = (M + 31) / 32;
-    const int ks = M >= 4096 ? 1 : 2;   // k-blocks of 32 features per LDS stage
+    const int upb = dtype == DVQ_F32 ? 4 : 2;
+    // k-blocks of 32 features per LDS stage (an fp32 stage of one block is as large as a bf16 stage of two)
+    const int ks = (dtype == DVQ_F32 || M >= 4096) ? 1 : 2;
     for (int j = 0; j < n_jobs; ++j)
         for (int t = 0; t < jobs[j].n_taps; ++t)
             if (jobs[j].taps[t].k_blocks % 2) return fail(DVQ_EINVAL, "prior_gemm: k_blocks must be even");
@@ -631,26 +722,29 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
     const int64_t want = 2 * kNumCU;
     const int no = ((int64_t)(N / 128) * gy * n_jobs >= want || (N % 64) != 0 || (epilogue == PG_GATE && (N % 128) != 0)) ? 4 : 2;
     const dim3 grid(N / (32 * no), gy, n_jobs);
-    const size_t lds = (size_t)kPgRing * (no * ks * 2 + kPgWaves * ks * 2) * 1024;
+    const size_t lds = (size_t)kPgRing * (no * ks * upb + kPgWaves * ks * upb) * 1024;
     hipStream_t st = as_stream(stream);
     const dim3 blk(kPgWaves * 64);
-#define DVQ_PG_LAUNCH2(E, NO_, KS_)                                                                      \
+#define DVQ_PG_LAUNCH3(D, E, NO_, KS_)                                                                   \
     do {                                                                                                 \
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_gemm_kernel<E, NO_, KS_>), lds, "prior_gemm")) return rc; \
-        hipLaunchKernelGGL((prior_gemm_kernel<E, NO_, KS_>), grid, blk, lds, st, dev, M, N, relu);       \
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_gemm_kernel<D, E, NO_, KS_>), lds, "prior_gemm")) return rc; \
+        hipLaunchKernelGGL((prior_gemm_kernel<D, E, NO_, KS_>), grid, blk, lds, st, dev, M, N, relu);    \
     } while (0)
-#define DVQ_PG_LAUNCH(E)                                  \
-    do {                                                  \
-        if (no == 4 && ks == 1) DVQ_PG_LAUNCH2(E, 4, 1);  \
-        else if (no == 4) DVQ_PG_LAUNCH2(E, 4, 2);        \
-        else if (ks == 1) DVQ_PG_LAUNCH2(E, 2, 1);        \
-        else DVQ_PG_LAUNCH2(E, 2, 2);                     \
+#define DVQ_PG_LAUNCH(E)                                                   \
+    do {                                                                   \
+        if (dtype == DVQ_F32) {                                            \
+            if (no == 4) DVQ_PG_LAUNCH3(DVQ_F32, E, 4, 1);                 \
+            else DVQ_PG_LAUNCH3(DVQ_F32, E, 2, 1);                         \
+        } else if (no == 4 && ks == 1) DVQ_PG_LAUNCH3(DVQ_BF16, E, 4, 1);  \
+        else if (no == 4) DVQ_PG_LAUNCH3(DVQ_BF16, E, 4, 2);               \
+        else if (ks == 1) DVQ_PG_LAUNCH3(DVQ_BF16, E, 2, 1);               \
+        else DVQ_PG_LAUNCH3(DVQ_BF16, E, 2, 2);                            \
     } while (0)
     if (epilogue == PG_PACK) DVQ_PG_LAUNCH(PG_PACK);
     else if (epilogue == PG_GATE) DVQ_PG_LAUNCH(PG_GATE);
     else if (epilogue == PG_ROWS) DVQ_PG_LAUNCH(PG_ROWS);
     else return fail(DVQ_EINVAL, "prior_gemm: unknown epilogue %d", epilogue);
-#undef DVQ_PG_LAUNCH2
+#undef DVQ_PG_LAUNCH3
 #undef DVQ_PG_LAUNCH
     return check_launch("prior_gemm");
 }

@@ -77,12 +77,12 @@ SIGNATURES = {
                                    c_int, c_int, POINTER(c_void_p), c_int64, c_int, c_void_p]),
     "dvq_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "dvq_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
-    "dvq_prior_packed_bytes": (c_size_t, [c_int, c_int]),
-    "dvq_prior_pack_weight": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
-    "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "dvq_prior_gemm": (c_int, [POINTER(DvqPriorJob), c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dvq_prior_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dvq_prior_pack_weight": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dvq_prior_gemm": (c_int, [POINTER(DvqPriorJob), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dvq_prior_vrow": (c_int, [POINTER(DvqPriorVRow), c_int, c_int, c_void_p]),
-    "dvq_prior_sample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "dvq_prior_sample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
     "dvq_mano_lbs_backward": (c_int, [c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,

@@ -397,33 +397,33 @@ def tta_contact_grad(obj: torch.Tensor, verts: torch.Tensor, mesh: DvqHandMesh, 
 PRIOR_PACK, PRIOR_GATE, PRIOR_ROWS = 0, 1, 2
 
 
-def prior_packed_empty(rows: int, features: int, device, zero: bool = False) -> torch.Tensor:
-    """Buffer for `rows` x `features` activations in the packed bf16 layout of the prior kernels."""
-    n = _lib.load().dvq_prior_packed_bytes(rows, features)
+def prior_packed_empty(rows: int, features: int, device, zero: bool = False, dtype_code: int = DVQ_BF16) -> torch.Tensor:
+    """Buffer for `rows` x `features` activations in the packed layout of the prior kernels (bf16 or fp32)."""
+    n = _lib.load().dvq_prior_packed_bytes(rows, features, dtype_code)
     if n == 0:
         raise RuntimeError("prior_packed_empty: features must be a positive multiple of 32")
     return (torch.zeros if zero else torch.empty)(n, dtype=torch.uint8, device=device)
 
 
-def prior_pack_weight(W: torch.Tensor) -> torch.Tensor:
-    """W [N, K] fp32 (any strides, e.g. one kernel tap of a conv weight) -> packed bf16."""
+def prior_pack_weight(W: torch.Tensor, dtype_code: int = DVQ_BF16) -> torch.Tensor:
+    """W [N, K] fp32 (any strides, e.g. one kernel tap of a conv weight) -> packed bf16 or fp32."""
     if not W.is_cuda or W.dtype != torch.float32 or W.dim() != 2:
         raise RuntimeError("prior_pack_weight: a 2-D float32 HIP tensor is required")
     N, K = W.shape
-    out = torch.empty(N * K * 2, dtype=torch.uint8, device=W.device)
+    out = torch.empty(N * K * (4 if dtype_code == DVQ_F32 else 2), dtype=torch.uint8, device=W.device)
     with torch.cuda.device(W.device):
-        rc = _lib.load().dvq_prior_pack_weight(_p(W), W.stride(0), W.stride(1), N, K, _p(out), _stream(W))
+        rc = _lib.load().dvq_prior_pack_weight(_p(W), W.stride(0), W.stride(1), N, K, dtype_code, _p(out), _stream(W))
     _lib.check(rc, "dvq_prior_pack_weight")
     return out
 
 
-def prior_embed(idx: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+def prior_embed(idx: torch.Tensor, table: torch.Tensor, out: torch.Tensor, dtype_code: int = DVQ_BF16) -> torch.Tensor:
     """out (packed) <- table[idx]; idx is a 1-D int64 view (may be strided)."""
     _need_gpu(table, out)
     M = idx.shape[0]
     V, d = table.shape
     with torch.cuda.device(table.device):
-        rc = _lib.load().dvq_prior_embed(_p(idx), idx.stride(0), _p(table), V, M, d, _p(out), _stream(table))
+        rc = _lib.load().dvq_prior_embed(_p(idx), idx.stride(0), _p(table), V, M, d, dtype_code, _p(out), _stream(table))
     _lib.check(rc, "dvq_prior_embed")
     return out
 
@@ -443,15 +443,15 @@ def prior_job(taps, bias, cond=None, label=None, resid=None, out_packed=None, ou
     return j
 
 
-def prior_gemm(jobs, M: int, N: int, epilogue: int, relu: bool, ref: torch.Tensor) -> None:
+def prior_gemm(jobs, M: int, N: int, epilogue: int, relu: bool, ref: torch.Tensor, dtype_code: int = DVQ_BF16) -> None:
     arr = (DvqPriorJob * len(jobs))(*jobs)
     with torch.cuda.device(ref.device), _timed("prior_gemm", (M, N, len(jobs)), ref):
-        rc = _lib.load().dvq_prior_gemm(arr, len(jobs), M, N, epilogue, int(relu), _stream(ref))
+        rc = _lib.load().dvq_prior_gemm(arr, len(jobs), M, N, epilogue, int(relu), dtype_code, _stream(ref))
     _lib.check(rc, "dvq_prior_gemm")
 
 
 def prior_sample(logits: torch.Tensor, u: torch.Tensor, x_out: torch.Tensor, table: Optional[torch.Tensor] = None,
-                 emb_out: Optional[torch.Tensor] = None) -> None:
+                 emb_out: Optional[torch.Tensor] = None, dtype_code: int = DVQ_BF16) -> None:
     """x_out[m] <- inverse-CDF draw from softmax(logits[m]) at uniform u[m]; u and x_out may be strided columns of
     [M, cells] tensors.  With `table`/`emb_out` the chosen embedding rows are written in packed form."""
     _need_gpu(logits)
@@ -462,7 +462,7 @@ def prior_sample(logits: torch.Tensor, u: torch.Tensor, x_out: torch.Tensor, tab
         raise RuntimeError("prior_sample: u and x_out must be 1-d views with one entry per row")
     with torch.cuda.device(logits.device):
         rc = _lib.load().dvq_prior_sample(_p(logits), n, M, _p(u), u.stride(0), _p(x_out), x_out.stride(0), _p(table),
-                                          0 if table is None else table.shape[1], _p(emb_out), _stream(logits))
+                                          0 if table is None else table.shape[1], dtype_code, _p(emb_out), _stream(logits))
     _lib.check(rc, "dvq_prior_sample")
 
 

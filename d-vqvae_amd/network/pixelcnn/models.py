@@ -27,6 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from dvq_hip import ops
+from dvq_hip._lib import DVQ_BF16, DVQ_F32
 from dvq_hip.rng import sample_rows
 
 
@@ -78,47 +79,22 @@ class GatedMaskedConv2d(nn.Module):
         return out_v, out_h
 
 
-class _Taps:
-    """Per-layer weights re-laid for the incremental evaluation: one [K, N] matrix per
-    kernel tap that can touch the grid, already transposed for row-major products."""
-
-    def __init__(self, layer: GatedMaskedConv2d, dtype):
-        k = layer.kernel
-        wv = layer.vert_stack.weight.detach()      # [2d, d, k//2+1, k]
-        wh = layer.horiz_stack.weight.detach()     # [2d, d, 1, k//2+1]
-        rows = k // 2 + 1
-        if layer.mask_type == 'A':                 # last kernel row / column is masked out (models.py:61-63)
-            vrows, hcols = range(rows - 1), range(rows - 1)
-        else:
-            vrows, hcols = range(rows), range(rows)
-        # vertical tap (a, b): input row i - k//2 + a, input col j - k//2 + b
-        self.vert = {(a - k // 2, b - k // 2): wv[:, :, a, b].t().contiguous().to(dtype) for a in vrows for b in range(k)}
-        # horizontal tap b: input col j - k//2 + b
-        self.horiz = {b - k // 2: wh[:, :, 0, b].t().contiguous().to(dtype) for b in hcols}
-        self.vert_bias = layer.vert_stack.bias.detach().float()
-        self.horiz_bias = layer.horiz_stack.bias.detach().float()
-        self.v2h = layer.vert_to_horiz.weight.detach()[:, :, 0, 0].t().contiguous().to(dtype)
-        self.v2h_bias = layer.vert_to_horiz.bias.detach().float()
-        self.resid = layer.horiz_resid.weight.detach()[:, :, 0, 0].t().contiguous().to(dtype)
-        self.resid_bias = layer.horiz_resid.bias.detach().float()
-        self.cond = layer.class_cond_embedding.weight.detach().float()
-        self.residual = layer.residual
-
-
 class _PackedTaps:
-    """The same per-tap matrices as _Taps, packed for the HIP products (dvq_prior_gemm):
-    bf16 A-operand fragment order, biases and class embeddings in fp32."""
+    """Per-layer weights re-laid for the incremental evaluation: one matrix per kernel tap that can touch the
+    grid, packed for the HIP products (dvq_prior_gemm) in A-operand fragment order -- bf16, or fp32 for the
+    parity configuration; biases and class embeddings stay fp32."""
 
-    def __init__(self, layer: GatedMaskedConv2d):
+    def __init__(self, layer: GatedMaskedConv2d, code: int):
         k = layer.kernel
+        pack = lambda w: ops.prior_pack_weight(w, code)
         wv = layer.vert_stack.weight.detach().float()
         wh = layer.horiz_stack.weight.detach().float()
         rows = k // 2 + 1
         live = range(rows - 1) if layer.mask_type == 'A' else range(rows)
-        self.vert = {(a - k // 2, b - k // 2): ops.prior_pack_weight(wv[:, :, a, b]) for a in live for b in range(k)}
-        self.horiz = {b - k // 2: ops.prior_pack_weight(wh[:, :, 0, b]) for b in live}
-        self.v2h = ops.prior_pack_weight(layer.vert_to_horiz.weight.detach().float()[:, :, 0, 0])
-        self.resid = ops.prior_pack_weight(layer.horiz_resid.weight.detach().float()[:, :, 0, 0])
+        self.vert = {(a - k // 2, b - k // 2): pack(wv[:, :, a, b]) for a in live for b in range(k)}
+        self.horiz = {b - k // 2: pack(wh[:, :, 0, b]) for b in live}
+        self.v2h = pack(layer.vert_to_horiz.weight.detach().float()[:, :, 0, 0])
+        self.resid = pack(layer.horiz_resid.weight.detach().float()[:, :, 0, 0])
         self.vert_bias = layer.vert_stack.bias.detach().float().contiguous()
         # the horizontal stack adds the projected vertical features before its gate (models.py:79-81)
         self.horiz_bias = (layer.horiz_stack.bias.detach().float() + layer.vert_to_horiz.bias.detach().float()).contiguous()
@@ -140,13 +116,13 @@ class GatedPixelCNN(nn.Module):
         self.output_conv = nn.Sequential(nn.Conv2d(dim, 2048, 1), nn.ReLU(True), nn.Conv2d(2048, input_dim, 1))
         self.apply(weights_init)
         self.compute_dtype = torch.float32     # operand precision of the matrix products in generate()
-        self._taps_key = None
-        self._taps = None
         self._packed_key = None
         self._packed = None
         self._bufs = {}
-        self._bufs32 = {}
-        self.use_graph = True                  # replay generate() as a captured HIP graph (bf16 kernels)
+        self.use_graph = True                  # replay generate() as a captured HIP graph
+        self.split = 1                         # sub-batches evaluated side by side (own streams and graphs)
+        self.split_min_rows = 2048             # ... for batches of at least this many rows
+        self.vrow_min_rows = 3072              # fused vertical-row kernel (bf16) from this many rows per (sub-)batch
 
     def forward(self, x, label):
         shp = x.size() + (-1,)
@@ -157,51 +133,50 @@ class GatedPixelCNN(nn.Module):
         return self.output_conv(x_h)
 
     # ------------------------------------------------------------------ sampling
-    def _prepared(self):
-        key = (tuple((p.data_ptr(), p._version) for p in self.parameters()), self.compute_dtype)
-        if key != self._taps_key:
-            dt = self.compute_dtype
-            head = (self.output_conv[0].weight.detach()[:, :, 0, 0].t().contiguous().to(dt),
-                    self.output_conv[0].bias.detach().float(),
-                    self.output_conv[2].weight.detach()[:, :, 0, 0].t().contiguous().to(dt),
-                    self.output_conv[2].bias.detach().float())
-            self._taps = ([_Taps(layer, dt) for layer in self.layers], head)
-            self._taps_key = key
-        return self._taps
+    def _code(self):
+        if self.compute_dtype == torch.bfloat16:
+            return DVQ_BF16
+        if self.compute_dtype == torch.float32:
+            return DVQ_F32
+        raise RuntimeError(f"GatedPixelCNN: compute_dtype {self.compute_dtype} (float32 or bfloat16 expected)")
+
+    def _weights_key(self):
+        return (tuple((p.data_ptr(), p._version) for p in self.parameters()), self._code())
 
     def _prepared_hip(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = self._weights_key()
         if key != self._packed_key:
-            head = (ops.prior_pack_weight(self.output_conv[0].weight.detach().float()[:, :, 0, 0]),
+            code = key[1]
+            head = (ops.prior_pack_weight(self.output_conv[0].weight.detach().float()[:, :, 0, 0], code),
                     self.output_conv[0].bias.detach().float().contiguous(),
-                    ops.prior_pack_weight(self.output_conv[2].weight.detach().float()[:, :, 0, 0]),
+                    ops.prior_pack_weight(self.output_conv[2].weight.detach().float()[:, :, 0, 0], code),
                     self.output_conv[2].bias.detach().float().contiguous())
-            self._packed = ([_PackedTaps(layer) for layer in self.layers], head)
+            self._packed = ([_PackedTaps(layer, code) for layer in self.layers], head)
             self._packed_key = key
             self._bufs = {}
         return self._packed
 
     def graph_ready(self, batch_size, shape=(3, 3)):
         """False when the next generate(..., uniforms=u) of this batch size will record a HIP graph (first call of a
-        batch size, or weights changed since): callers with asynchronous work of their own in flight (a pending
-        collective) complete it first.  True when a recorded graph will be replayed or none is used."""
+        batch size, or weights or precision changed since): callers with asynchronous work of their own in flight (a
+        pending collective) complete it first.  True when a recorded graph will be replayed or none is used."""
         if not self.use_graph or not self.embedding.weight.is_cuda:
             return True
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        dev = str(self.embedding.weight.device)
-        if self.compute_dtype == torch.bfloat16:
-            b = self._bufs.get((batch_size, shape[0], shape[1], dev))
-            return key == self._packed_key and b is not None and b.get("graph") is not None
-        st = self._bufs32.get(("f32", batch_size, shape[0], shape[1], dev))
-        return st is not None and getattr(self, "_bufs32_key", None) == (key, self.compute_dtype)
+        b = self._bufs.get((batch_size, shape[0], shape[1], str(self.embedding.weight.device)))
+        return (self._weights_key() == self._packed_key and b is not None and b.get("graph") is not None
+                and b.get("split") == (self._n_parts(batch_size), self.vrow_min_rows))
 
-    def _act_buffers(self, B, H, W, dev):
-        """Packed activation buffers for a batch of B grids, allocated once per (B, H, W)."""
-        key = (B, H, W, str(dev))
+    def _act_buffers(self, B, H, W, dev, part=None):
+        """Packed activation buffers for a batch of B grids, allocated once per (B, H, W); `part` tells the
+        buffer sets of the sub-batches of one split batch apart.  A new batch size drops the old buffers."""
+        key = (B, H, W, str(dev)) if part is None else (B, H, W, str(dev), part)
         if key not in self._bufs:
             L, d = len(self.layers), self.dim
-            e = lambda f, zero=False: ops.prior_packed_empty(B, f, dev, zero)
-            self._bufs = {key: dict(
+            code = self._code()
+            e = lambda f, zero=False: ops.prior_packed_empty(B, f, dev, zero, code)
+            if part is None:
+                self._bufs = {}
+            self._bufs[key] = dict(
                 XV=[[[e(d) for _ in range(W)] for _ in range(H)] for _ in range(L + 1)],
                 HV=[[e(2 * d) for _ in range(W)] for _ in range(L)],
                 XH=[[e(d) for _ in range(L + 1)] for _ in range(2)],
@@ -209,51 +184,100 @@ class GatedPixelCNN(nn.Module):
                 logits=torch.empty(B, self.output_conv[2].out_channels, dtype=torch.float32, device=dev),
                 emb=self.embedding.weight.detach().float().contiguous(),
                 label=torch.zeros(B, dtype=torch.int64, device=dev),
-                u=torch.zeros(B, H * W, dtype=torch.float64, device=dev), graph=None, x=None)}
+                u=torch.zeros(B, H * W, dtype=torch.float64, device=dev), graph=None, x=None)
         return self._bufs[key]
 
     @torch.no_grad()
-    def _generate_hip(self, label, shape, B, generator, return_probs, uniforms):
-        """generate() on the fused bf16 kernels.  With explicit uniforms the whole procedure is a
-        fixed sequence of ~370 launches over persistent buffers; it is captured once per batch
-        size into a HIP graph and replayed, because issuing that many small dependent launches
-        from Python costs more than running them."""
+    def generate(self, x_start, label, shape=(3, 3), batch_size=64, generator=None, return_probs=False,
+                 uniforms=None):
+        """Sample a grid of indices, cell by cell in raster order (models.py:176-198).
+        `x_start` is accepted and ignored, as in the reference.  Cell (i,j) is drawn from
+        softmax(logits[:, :, i, j]) with torch.multinomial (optionally `generator`) or, when
+        `uniforms` [B, H*W] is given, by inverse CDF.
+
+        The products run on the HIP kernels of dvq_prior_gemm in `compute_dtype`: float32 (exact fp32, the
+        reference's arithmetic) or bfloat16 operands with fp32 accumulation.  With explicit uniforms the whole
+        procedure is a fixed sequence of ~370 launches over persistent buffers; it is captured once per batch
+        size into a HIP graph and replayed, because issuing that many small dependent launches from Python
+        costs more than running them."""
         H, W = shape
+        B = batch_size
         dev = self.embedding.weight.device
+        if not self.embedding.weight.is_cuda:
+            raise RuntimeError("GatedPixelCNN.generate needs the module on a HIP device (there is no CPU path)")
         self._prepared_hip()
         bufs = self._act_buffers(B, H, W, dev)
         bufs["label"].copy_(label.reshape(-1).to(torch.int64))
         if uniforms is None or return_probs or not self.use_graph:
             return self._run_hip(bufs, shape, B, generator, return_probs, uniforms)
         bufs["u"].copy_(uniforms)
-        if bufs.get("graph") is None:
-            self._run_hip(bufs, shape, B, None, False, bufs["u"])        # warm-up outside capture
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                bufs["x"] = self._run_hip(bufs, shape, B, None, False, bufs["u"])
-            bufs["graph"] = g
-        bufs["graph"].replay()
+        if bufs.get("graph") is None or bufs.get("split") != (self._n_parts(B), self.vrow_min_rows):
+            n_parts = self._n_parts(B)
+            parts = None
+            if n_parts > 1:
+                # Rows are independent: the sub-batches run the same chain on streams of their own, one's launch
+                # boundaries under the other's work.
+                per = (B + n_parts - 1) // n_parts // 32 * 32
+                cuts = [min(B, k * per) for k in range(n_parts)] + [B]
+                parts = [(a, b, self._act_buffers(b - a, H, W, dev, part=(B, k)), torch.cuda.Stream(device=dev))
+                         for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
+            if parts is None:
+                self._run_hip(bufs, shape, B, None, False, bufs["u"])    # warm-up outside capture
+                torch.cuda.synchronize(dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    bufs["x"] = self._run_hip(bufs, shape, B, None, False, bufs["u"])
+                graphs = [g]
+            else:
+                # one graph per sub-batch, replayed on streams of their own (the branches of ONE graph were
+                # seen to run one after the other)
+                bufs["x"] = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
+                graphs = []
+                for a, b, pb, st in parts:
+                    self._run_hip(pb, shape, b - a, None, False, bufs["u"][a:b], x_out=bufs["x"][a:b])
+                    torch.cuda.synchronize(dev)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        pb["label"].copy_(bufs["label"][a:b])
+                        self._run_hip(pb, shape, b - a, None, False, bufs["u"][a:b], x_out=bufs["x"][a:b])
+                    graphs.append(g)
+            bufs["graph"], bufs["split"], bufs["parts"] = graphs, (n_parts, self.vrow_min_rows), parts
+        if bufs["parts"] is None:
+            bufs["graph"][0].replay()
+        else:
+            main = torch.cuda.current_stream(dev)
+            for g, (_, _, _, st) in zip(bufs["graph"], bufs["parts"]):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    g.replay()
+            for _, _, _, st in bufs["parts"]:
+                main.wait_stream(st)
         return bufs["x"].clone()
 
-    def _run_hip(self, bufs, shape, B, generator, return_probs, uniforms):
+    def _n_parts(self, B):
+        return self.split if (self.split > 1 and B >= self.split_min_rows) else 1
+
+    def _run_hip(self, bufs, shape, B, generator, return_probs, uniforms, x_out=None):
         """Per grid row one launch per layer for the vertical stack (3 cells at once, gate fused), per
         cell two launches per layer for the horizontal stack (taps + projected vertical features +
         gate; residual 1x1), two for the head, then the sample and its embedding."""
         H, W = shape
         layers, (wo1, bo1, wo2, bo2) = self._packed
+        code = self._packed_key[1]
         dev = self.embedding.weight.device
         XV, HV, XHb, OUT, HID, Z, logits = (bufs[k] for k in ("XV", "HV", "XH", "OUT", "HID", "Z", "logits"))
         L, d = len(layers), self.dim
         kb = d // 32
         emb = bufs["emb"]
         label = bufs["label"]
-        x = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
+        x = torch.zeros((B, H, W), dtype=torch.int64, device=dev) if x_out is None else x_out
         n_out = logits.shape[1]
         probs_all = []
+        gemm = lambda jobs, N, epi, relu=False: ops.prior_gemm(jobs, B, N, epi, relu, emb, code)
         for i in range(H):
             for l, t in enumerate(layers):
-                if W == 3 and t.kernel == 3 and not t.mask_a and B >= 3072:   # smaller batches are latency-bound: per-cell launches
+                if code == DVQ_BF16 and W == 3 and t.kernel == 3 and not t.mask_a and B >= self.vrow_min_rows:
+                    # (smaller batches are latency-bound: per-cell launches)
                     # all three cells of the row in one launch: every input column and every tap is fetched once
                     rows = [([XV[l][i + da][c] for c in range(3)], [t.vert[(da, db)] for db in (-1, 0, 1)])
                             for da in (-1, 0) if i + da >= 0]
@@ -268,7 +292,7 @@ class GatedPixelCNN(nn.Module):
                         taps = [(Z, next(iter(t.vert.values())), kb)]
                     jobs.append(ops.prior_job(taps, t.vert_bias, cond=t.cond, label=label, out_packed=XV[l + 1][i][j],
                                               out_pre=HV[l][j]))
-                ops.prior_gemm(jobs, B, 2 * d, ops.PRIOR_GATE, False, emb)
+                gemm(jobs, 2 * d, ops.PRIOR_GATE)
             for j in range(W):
                 XH, XHp = XHb[j & 1], XHb[(j & 1) ^ 1]
                 for l, t in enumerate(layers):
@@ -284,16 +308,14 @@ class GatedPixelCNN(nn.Module):
                         elif c == j - 1:
                             taps.append((XHp[l], w, kb))
                     taps.append((HV[l][j], t.v2h, 2 * kb))
-                    ops.prior_gemm([ops.prior_job(taps, t.horiz_bias, cond=t.cond, label=label, out_packed=OUT)],
-                                   B, 2 * d, ops.PRIOR_GATE, False, emb)
-                    ops.prior_gemm([ops.prior_job([(OUT, t.resid, kb)], t.resid_bias, resid=XH[l] if t.residual else None,
-                                                  out_packed=XH[l + 1])], B, d, ops.PRIOR_PACK, False, emb)
-                ops.prior_gemm([ops.prior_job([(XH[L], wo1, kb)], bo1, out_packed=HID)], B, bo1.numel(), ops.PRIOR_PACK, True, emb)
-                ops.prior_gemm([ops.prior_job([(HID, wo2, bo1.numel() // 32)], bo2, out_rows=logits)], B, n_out, ops.PRIOR_ROWS,
-                               False, emb)
+                    gemm([ops.prior_job(taps, t.horiz_bias, cond=t.cond, label=label, out_packed=OUT)], 2 * d, ops.PRIOR_GATE)
+                    gemm([ops.prior_job([(OUT, t.resid, kb)], t.resid_bias, resid=XH[l] if t.residual else None,
+                                        out_packed=XH[l + 1])], d, ops.PRIOR_PACK)
+                gemm([ops.prior_job([(XH[L], wo1, kb)], bo1, out_packed=HID)], bo1.numel(), ops.PRIOR_PACK, True)
+                gemm([ops.prior_job([(HID, wo2, bo1.numel() // 32)], bo2, out_rows=logits)], n_out, ops.PRIOR_ROWS)
                 if uniforms is not None and not return_probs:
                     # softmax, draw, grid write and embedding of the drawn code in one launch
-                    ops.prior_sample(logits, uniforms[:, i * W + j], x[:, i, j], emb, XV[0][i][j])
+                    ops.prior_sample(logits, uniforms[:, i * W + j], x[:, i, j], emb, XV[0][i][j], code)
                     continue
                 probs = F.softmax(logits, -1)
                 probs = probs / probs.sum(dim=1, keepdim=True)
@@ -303,133 +325,7 @@ class GatedPixelCNN(nn.Module):
                     x[:, i, j] = sample_rows(probs, uniforms[:, i * W + j].contiguous())
                 else:
                     x[:, i, j] = probs.multinomial(1, generator=generator).squeeze(1)
-                ops.prior_embed(x[:, i, j], emb, XV[0][i][j])
-        if return_probs:
-            return x, torch.stack(probs_all, 1)
-        return x
-
-    @staticmethod
-    def _mm(acc, a, w):
-        """acc += a @ w with fp32 accumulation/output; a, w in the compute dtype."""
-        if a.dtype == torch.float32:
-            return acc.addmm_(a, w)
-        return acc.add_(torch.mm(a, w).float()) if acc is not None else torch.mm(a, w).float()
-
-    @staticmethod
-    def _gate(y):
-        d = y.shape[1] // 2
-        return torch.tanh(y[:, :d]) * torch.sigmoid(y[:, d:])
-
-    @torch.no_grad()
-    def generate(self, x_start, label, shape=(3, 3), batch_size=64, generator=None, return_probs=False,
-                 uniforms=None):
-        """Sample a grid of indices, cell by cell in raster order (models.py:176-198).
-        `x_start` is accepted and ignored, as in the reference.  Cell (i,j) is drawn from
-        softmax(logits[:, :, i, j]) with torch.multinomial (optionally `generator`) or, when
-        `uniforms` [B, H*W] is given, by inverse CDF."""
-        H, W = shape
-        if self.compute_dtype == torch.bfloat16:
-            return self._generate_hip(label, shape, batch_size, generator, return_probs, uniforms)
-        if uniforms is None or return_probs or not self.use_graph or not self.embedding.weight.is_cuda:
-            return self._generate_torch(label, shape, batch_size, generator, return_probs, uniforms)
-        # With explicit uniforms the float32 procedure is a fixed sequence of ~2000 small launches as well:
-        # record it once per batch size and replay it.
-        self._prepared()
-        key = ("f32", batch_size, H, W, str(self.embedding.weight.device))
-        st = self._bufs32.get(key) if getattr(self, "_bufs32_key", None) == self._taps_key else None
-        if st is None:
-            dev = self.embedding.weight.device
-            st = dict(label=torch.zeros(batch_size, dtype=torch.int64, device=dev),
-                      u=torch.zeros(batch_size, H * W, dtype=torch.float64, device=dev), graph=None, x=None)
-            st["label"].copy_(label.reshape(-1).to(torch.int64))
-            st["u"].copy_(uniforms)
-            self._generate_torch(st["label"], shape, batch_size, None, False, st["u"])      # warm-up outside capture
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                st["x"] = self._generate_torch(st["label"], shape, batch_size, None, False, st["u"])
-            st["graph"] = g
-            self._bufs32 = {key: st}
-            self._bufs32_key = self._taps_key
-        st["label"].copy_(label.reshape(-1).to(torch.int64))
-        st["u"].copy_(uniforms)
-        st["graph"].replay()
-        return st["x"].clone()
-
-    @torch.no_grad()
-    def _generate_torch(self, label, shape, batch_size, generator, return_probs, uniforms):
-        """generate() in the compute dtype on torch matrix products (the float32 parity configuration)."""
-        H, W = shape
-        layers, (wo1, bo1, wo2, bo2) = self._prepared()
-        dt = self.compute_dtype
-        dev = self.embedding.weight.device
-        B = batch_size
-        L = len(layers)
-        emb = self.embedding.weight.detach()
-        label = label.reshape(-1).to(torch.int64)
-        cond = [t.cond[label] for t in layers]                         # [B, 2d] per layer
-        x = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
-        # XV[l][i][j]: input of layer l's vertical stack at cell (i,j), [B, d] in the compute dtype
-        XV = [[[None] * W for _ in range(H)] for _ in range(L + 1)]
-        probs_all = []
-
-        def lin(bias, pairs, n_out):
-            """bias + sum_k a_k @ w_k, fp32 [B, n_out]"""
-            acc = bias.unsqueeze(0).repeat(B, 1)        # a fresh buffer (expand().contiguous() aliases the bias when B == 1)
-            for a, w in pairs:
-                if a.dtype == torch.float32:
-                    acc.addmm_(a, w)
-                else:
-                    acc.add_(torch.mm(a, w))
-            return acc
-
-        for i in range(H):
-            # ---- vertical stack of row i, all layers (sees rows < i only) + projection to the horizontal stack
-            v2h = [[None] * W for _ in range(L)]
-            for l, t in enumerate(layers):
-                for j in range(W):
-                    pairs = []
-                    for (da, db), w in t.vert.items():
-                        r, c = i + da, j + db
-                        if 0 <= r < H and 0 <= c < W and XV[l][r][c] is not None:
-                            pairs.append((XV[l][r][c], w))
-                    hv = lin(t.vert_bias, pairs, t.vert_bias.numel())
-                    XV[l + 1][i][j] = self._gate(hv + cond[l]).to(dt)
-                    v2h[l][j] = lin(t.v2h_bias, [(hv.to(dt), t.v2h)], t.v2h_bias.numel())
-            # ---- the cells of row i, left to right
-            XH_prev = None                                           # layer inputs of the cell to the left
-            for j in range(W):
-                XH = [None] * (L + 1)
-                for l, t in enumerate(layers):
-                    pairs = []
-                    for db, w in t.horiz.items():
-                        c = j + db
-                        if c < 0:
-                            continue
-                        if l == 0:
-                            src = XV[0][i][c]                         # embeddings of the sampled cells of this row
-                        else:
-                            src = XH[l] if c == j else (XH_prev[l] if c == j - 1 else None)
-                        if src is not None:
-                            pairs.append((src, w))
-                    hh = lin(t.horiz_bias, pairs, t.horiz_bias.numel())
-                    out = self._gate(v2h[l][j] + hh + cond[l]).to(dt)
-                    nxt = lin(t.resid_bias, [(out, t.resid)], t.resid_bias.numel())
-                    if t.residual:
-                        nxt = nxt + XH[l].float()
-                    XH[l + 1] = nxt.to(dt)
-                hid = torch.relu_(lin(bo1, [(XH[L], wo1)], bo1.numel())).to(dt)
-                logits = lin(bo2, [(hid, wo2)], bo2.numel())
-                probs = F.softmax(logits, -1)
-                probs = probs / probs.sum(dim=1, keepdim=True)
-                if return_probs:
-                    probs_all.append(probs)
-                if uniforms is not None:
-                    x[:, i, j] = sample_rows(probs, uniforms[:, i * W + j].contiguous())
-                else:
-                    x[:, i, j] = probs.multinomial(1, generator=generator).squeeze(1)
-                XV[0][i][j] = emb[x[:, i, j]].to(dt)                  # this cell is now an input of later ones
-                XH_prev = XH
+                ops.prior_embed(x[:, i, j], emb, XV[0][i][j], code)
         if return_probs:
             return x, torch.stack(probs_all, 1)
         return x

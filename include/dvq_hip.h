@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 106   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 107   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -236,9 +236,11 @@ int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, int64_t obj
 /* ------------------------------------------------------------ prior (PixelCNN)
  * Matrix products of the GatedPixelCNN prior evaluated cell by cell (reference:
  * DVQ-VAE/network/pixelcnn/models.py:65-88 gated layer, :161-174 forward, :176-198 generate),
- * bf16 operands / fp32 accumulation, with the gate and residual fused.  Activations are kept
- * between calls in "packed" bf16 form (dvq_prior_packed_bytes(rows, features) bytes; layout
- * in csrc/prior_gemm.hip), weights are packed once by dvq_prior_pack_weight.
+ * with the gate and residual fused.  `dtype` DVQ_BF16: bf16 operands / fp32 accumulation (throughput configuration);
+ * DVQ_F32: exact fp32 on the 32x32x2 matrix instruction (the reference's arithmetic; parity configuration).
+ * Activations are kept between calls in "packed" form of that dtype (dvq_prior_packed_bytes(rows, features, dtype)
+ * bytes; layout in csrc/prior_gemm.hip), weights are packed once by dvq_prior_pack_weight; every buffer a call
+ * touches must have been packed for the same dtype.
  *
  * dvq_prior_gemm runs 1..3 independent jobs of the same shape in one launch.  A job computes
  *   y[m, :] = bias + sum over taps  W_tap * x_tap[m, :]        (N outputs, M rows)
@@ -271,16 +273,18 @@ typedef struct {
     float* out_rows;
 } DvqPriorJob;
 
-size_t dvq_prior_packed_bytes(int rows, int features);
+size_t dvq_prior_packed_bytes(int rows, int features, int dtype);
 /* W element (n,k) at W[n*ldn + k*ldk] (a kernel tap of a conv weight is a strided view) */
-int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K, void* out, void* stream);
+int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K, int dtype, void* out, void* stream);
 /* out(packed)[m] = table[idx[m*idx_stride]]: embedding rows of sampled indices, d features */
-int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, void* out, void* stream);
-int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, void* stream);
+int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, int dtype, void* out,
+                    void* stream);
+int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, int dtype, void* stream);
 /* Vertical stack of one grid row of a kernel-3 layer (models.py:72-73 for the three cells of a row at once):
  *   y_j = bias + sum over input rows r and columns c with |c - j| <= 1 of  w[r][c - j + 1] * x[r][c],   j = 0, 1, 2
  * followed by the GATE epilogue of dvq_prior_gemm per cell (out_packed[j]: N/2 features; out_pre[j], optional: N).
- * Same numbers as three dvq_prior_gemm jobs; each activation and weight unit is fetched once for all three cells. */
+ * Same numbers as three dvq_prior_gemm jobs; each activation and weight unit is fetched once for all three cells.
+ * bf16 buffers only. */
 typedef struct {
     const void* x[2][3];     /* packed activations of input row r, grid column c (32*k_blocks features) */
     const void* w[2][3];     /* packed weights [N, 32*k_blocks] of tap (row r, column offset -1, 0, +1) */
@@ -297,9 +301,9 @@ int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream);
 /* One cell of the sampling loop (models.py:189-196): p = softmax(logits[m, :]) / sum, x = inverse CDF of p at the
  * uniform u[m*u_stride] in [0,1) (fp64 running sum; the number of cdf entries <= u, clamped to n_classes-1), written to
  * x_out[m*x_stride]; if emb_out is given, row x of `table` [n_classes, d] is also written there as packed activations
- * (the next cell's input).  logits: fp32 [M, n_classes], n_classes <= 1024. */
+ * of `emb_dtype` (the next cell's input).  logits: fp32 [M, n_classes], n_classes <= 1024. */
 int dvq_prior_sample(const float* logits, int n_classes, int M, const double* u, int64_t u_stride, int64_t* x_out,
-                     int64_t x_stride, const float* table, int d, void* emb_out, void* stream);
+                     int64_t x_stride, const float* table, int d, int emb_dtype, void* emb_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,30 @@ def prior():
             print(f"prior.generate B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  ({1.22e9 * B / ms / 1e9:7.1f} TFLOP/s useful)", flush=True)
 
 
+def prior_split():
+    """prior.generate at 4096 rows with the batch cut into sub-batches on concurrent streams inside the graph."""
+    from network.gen_net import GenNet
+    from dvq_hip import rng
+    model = GenNet()
+    model.load_state_dict(synth.gennet_state_dict(0))
+    pr = model.GatedPixelCNN.to(dev).eval()
+    pr.compute_dtype = torch.bfloat16
+    B = 4096
+    lab = torch.randint(0, 128, (B,), device=dev)
+    u = rng.uniforms(torch.arange(B, device=dev), 9, 0)
+    ref = None
+    cfgs = ((1, 3072), (2, 3072), (2, 1024), (3, 1024), (4, 1024), (4, 512), (1, 3072))
+    if os.environ.get("DVQ_SPLIT"):
+        cfgs = ((int(os.environ["DVQ_SPLIT"]), 1024),)
+    for split, vmin in cfgs:
+        pr.split, pr.vrow_min_rows = split, vmin
+        ms = timeit(lambda: pr.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u), iters=5, warm=2)
+        x = pr.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u)
+        ref = x if ref is None else ref
+        print(f"prior.generate B={B} bf16 split={split} vrow_min={vmin}: {ms:8.3f} ms; cells equal to unsplit {(x == ref).float().mean().item():.4f}",
+              flush=True)
+
+
 def dvqvae():
     """The encode path (DVQVAE.forward, eval): two object encoders, six hand-part encoders + MLPs, seven codebook searches."""
     from network.DVQVAE import DVQVAE
@@ -145,8 +169,11 @@ def gen4096():
     from dvq_hip.pipeline import GraspGenerator
     g = GraspGenerator.synthetic(dev, seed=0, dtype=torch.bfloat16)
     obj = synth.object_clouds_device(4096, 3000, 11, dev)
-    ms = timeit(lambda: g.generate(obj), iters=10, warm=3)
-    print(f"generate B=4096 bf16: {ms:8.3f} ms  {4096 / ms * 1e3:10.0f} grasps/s", flush=True)
+    pr = g.model.GatedPixelCNN
+    for split, vmin in ((1, 3072), (2, 1024), (1, 3072), (2, 1024)):
+        pr.split, pr.vrow_min_rows = split, vmin
+        ms = timeit(lambda: g.generate(obj), iters=10, warm=3)
+        print(f"generate B=4096 bf16 split={split}: {ms:8.3f} ms  {4096 / ms * 1e3:10.0f} grasps/s", flush=True)
 
 
 def tta():
