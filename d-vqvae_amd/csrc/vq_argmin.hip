@@ -61,6 +61,7 @@ struct VqBatch {
 constexpr int kVqRotMinTiles = 8;          // 256 codes: four stages of two tiles
 constexpr int kVqRotMaxTiles = 64;
 constexpr int64_t kVqRotMinRows = 65536;   // below this the one-sweep kernel has the lower fixed cost
+constexpr int64_t kVqTwoTileMaxRows = (int64_t)3 << 20;
 
 // ------------------------------------------------------------------ pack kernel
 template <int DT>
@@ -468,8 +469,9 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_rot_kernel(
         if (row >= n) row = n - 1;
         const unsigned short* zr = z + row * D + 8 * q;
 #pragma unroll
-        for (int s = 0; s < S; ++s)   // read once: keep the stream out of the way of the codebook in L2
-            zp[s] = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(zr + 32 * s)));
+        // (plain loads: nontemporal ones measured 2-7 % slower here at 256..2048 codes, and 10 % slower in the one-sweep
+        // kernel beyond 4 Mi rows, although the rows are read once)
+        for (int s = 0; s < S; ++s) zp[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(zr + 32 * s));
     };
     auto store_tile = [&](int i, float bv, int bi) {
 #pragma unroll
@@ -925,6 +927,11 @@ static int launch_bf16_rot(const void* z, const char* ws, const VqPlan& p, int64
 template <int DT>
 static int launch_fast(const VqBatch& vb, int nb, const VqPlan& p, int64_t n, int D, hipStream_t st) {
     if (DT == DVQ_BF16) {
+        // A codebook that stays in LDS (up to 128 codes: the reference's size) leaves the search bound by the latent
+        // stream from HBM, i.e. by the bytes a CU keeps in flight: two latent tiles per wave need half the registers
+        // of four, so two workgroups (16 waves) share a CU and one loads while the other computes -- 4.7 -> 5.0 TB/s
+        // at 1 Mi latents, 3.4 -> 4.5 at 256 Ki; beyond a few Mi rows four tiles per wave are ahead again (5.2 vs 5.4).
+        if (D == 256 && p.n_tiles <= 4 && n <= kVqTwoTileMaxRows) return launch_bf16x<256, 2, 8>(vb, nb, p, n, st);
         if (D == 256) return launch_bf16x<256, 4, 8>(vb, nb, p, n, st);
         if (D == 128) return launch_bf16x<128, 4, 8>(vb, nb, p, n, st);
         return launch_bf16x<64, 4, 8>(vb, nb, p, n, st);

@@ -119,7 +119,7 @@ def test_vq_full_size_properties():
     assert (idx_b.cpu() == j).float().mean().item() > 0.9999
 
 
-@pytest.mark.parametrize("K", [256, 320, 512, 1000, 2048])
+@pytest.mark.parametrize("K", [100, 128, 256, 320, 512, 1000, 2048])
 def test_vq_bf16_long_codebook_rotating_sweep(K):
     """Many latents against a long bf16 codebook take the kernel whose latent tiles start their sweep at different
     quarters of the codebook.  Its result must equal, bit for bit, that of the one-sweep kernel (taken by slices below

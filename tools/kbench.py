@@ -63,6 +63,27 @@ def vq():
             del z, E, ws
 
 
+def vq_stream():
+    """How fast the latent stream of the reference codebook shape (128 x 256, bf16) goes as the batch grows, next to
+    plain reads of the same bytes (torch sum of the buffer as int32, and a device-to-device copy)."""
+    K, D = 128, 256
+    g = torch.Generator(dev).manual_seed(1)
+    E = torch.randn(K, D, device=dev, generator=g).to(torch.bfloat16)
+    ws = ops.vq_prepare(E)
+    for n in (1 << 18, 1 << 20, 1 << 22, 1 << 23):
+        z = torch.randn(n, D, device=dev, generator=g).to(torch.bfloat16)
+        idx = torch.empty(n, dtype=torch.int64, device=dev)
+        ms = timeit(lambda: ops.vq_argmin(z, E, want_zq=False, prepared=ws), iters=10)
+        by = n * D * 2 + 8 * n
+        zi = z.view(torch.int32)
+        ms_sum = timeit(lambda: zi.sum(), iters=10)
+        out = torch.empty_like(z)
+        ms_cp = timeit(lambda: out.copy_(z), iters=10)
+        print(f"n={n:8d}: vq_argmin {ms:7.4f} ms {by / ms / 1e6:7.1f} GB/s | int32 sum {ms_sum:7.4f} ms {n * D * 2 / ms_sum / 1e6:7.1f} GB/s"
+              f" | copy {ms_cp:7.4f} ms {2 * n * D * 2 / ms_cp / 1e6:7.1f} GB/s (read+write)", flush=True)
+        del z, out, zi, idx
+
+
 def vq_obj():
     """The object codebook search as gen() runs it: one 1024-d row per object, 128 codes, fp32."""
     for n in (4096, 256, 1):
