@@ -6,40 +6,69 @@
 // passes its own all-zero betas to lbs (model.py:335), so v_shaped = v_template and the
 // rest joints J = J_regressor * v_shaped are constants supplied by the host.
 //
-// The work is bandwidth-shaped: per hand 244 B in, 9.3 KB out and ~0.5 M multiply-adds,
-// of which the pose blend-shape product [135] x [135, 3V] is the bulk.  One workgroup
-// therefore takes HB hands at once so that every posedirs element fetched (coalesced,
-// 12 B per lane, L2-resident) feeds HB multiply-adds, and each lane owns whole vertices
-// so the [B,V,3] result is written as contiguous 12-B-per-lane rows.
+// Per hand: 244 B in, 9.3 KB out and ~0.5 M multiply-adds, of which the pose blend-shape product
+// [135] x [135, 3V] is the bulk.  A workgroup takes 16 hands:
+//   A  Rodrigues, one thread per (hand, joint);
+//   B  the kinematic chain, one thread per (hand, matrix row): row a of T_i = T_parent(i) [R_i | t_i] depends on
+//      row a of the parent alone, so the three rows of a hand advance side by side;
+//   C  per group of 16 vertices the blend shapes as a 16x16x4 fp32 MFMA product -- posedirs^T (16 vertices of one
+//      coordinate axis x 4 pose features) times the pose features (4 x 16 hands); the accumulator then holds, per lane,
+//      ONE hand and four whole vertices (the x, y and z tiles line up), so skinning continues in registers: the
+//      transform of a vertex is gathered from its few non-zero skinning weights (1-6 of 16; table of (joint, weight)
+//      pairs in ascending joint order, so the sum equals the reference's dense one bit for bit: the skipped terms are
+//      exact zeros), and the lane writes its four vertices as 48 contiguous bytes.
+// posedirs (1.26 MB, L2-resident) is read once per workgroup, 12 B per lane.
 #include "common.h"
 
 namespace dvq {
 
-constexpr int kHB = 8;        // hands per workgroup
+constexpr int kMH = 16;       // hands per workgroup
 constexpr int kJ = 16;        // joints
 constexpr int kPF = 135;      // pose-feature length = 15 joints * 9
-constexpr int kManoThreads = 256;
+constexpr int kKS = 34;       // MFMA k-steps of 4 over the pose features (135 + one zero)
+constexpr int kManoThreads = 256;    // phase A uses all of them (hand x joint), phase B the first 48, phase C four waves
+constexpr int kSkinW = 8;     // slots per vertex in the skinning table
 
-__global__ __launch_bounds__(kManoThreads, 2) void mano_lbs_kernel(
+struct f32x3 { float x, y, z; };
+
+// TABLE: skinning weights come as kSkinW (joint, weight) slots per vertex; otherwise as the dense [V,16] matrix.
+template <bool TABLE>
+__global__ __launch_bounds__(kManoThreads) void mano_lbs_kernel(
     const float* __restrict__ global_orient, const float* __restrict__ hand_pose, const float* __restrict__ transl,
     int B, int V, int ncomp, const float* __restrict__ v_shaped, const float* __restrict__ joints,
     const float* __restrict__ posedirs, const float* __restrict__ weights, const float* __restrict__ comps,
-    const float* __restrict__ pose_mean, const int* __restrict__ parents, float* __restrict__ verts_out,
+    const float* __restrict__ pose_mean, const int* __restrict__ parents, const unsigned char* __restrict__ skin_joints,
+    const float* __restrict__ skin_weights, float* __restrict__ verts_out,
     float* __restrict__ joints_out, float* __restrict__ full_pose_out, float* __restrict__ v_posed_out) {
-    __shared__ float sR[kHB][kJ][9];     // rotation matrices
-    __shared__ __attribute__((aligned(16))) float sA[kHB][kJ][12];    // relative transforms, upper 3x4
-    __shared__ float sT[kHB][kJ][12];    // world transforms, upper 3x4
-    __shared__ float sPF[kHB][kPF + 1];  // pose feature (R[1:] - I)
-    __shared__ float sTr[kHB][4];        // translation (0 when absent)
-    __shared__ float sVP[kHB][3][kManoThreads];  // posed vertex of each thread, per hand
+    __shared__ float sR[kMH][kJ][9];     // rotation matrices
+    // relative transforms, upper 3x4; 4 floats of padding per hand: the skinning gather reads sA[h][j] with h = lane & 15,
+    // and an unpadded hand stride (192 words) would put all sixteen hands on the same LDS banks
+    __shared__ __attribute__((aligned(16))) float sAp[kMH][kJ * 12 + 4];
+    auto sA = [&](int hh, int jj) -> float* { return &sAp[hh][jj * 12]; };
+    __shared__ float sT[kMH][kJ][12];    // world transforms, upper 3x4
+    __shared__ float sPF[kMH][kKS * 4];  // pose feature (R[1:] - I), zero-padded
+    __shared__ float sTr[kMH][4];        // translation (0 when absent)
+    __shared__ float sHP[kMH][48];       // PCA coefficients of the block's hands
+    __shared__ float sComps[45 * 45];    // PCA basis
+    __shared__ float sJ[kJ * 3];         // rest joints
+    __shared__ int sPar[kJ];
 
     const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * kHB;
-    const int nh = (B - b0) < kHB ? (B - b0) : kHB;
+    const int b0 = blockIdx.x * kMH;
+    const int nh = (B - b0) < kMH ? (B - b0) : kMH;
+
+    // Everything the two serial phases read goes to LDS in one round of coalesced loads: fetched where it is used
+    // (45 dependent steps of the PCA product, 16 of the chain) each load would cost a trip to L2.
+    for (int i = tid; i < nh * ncomp; i += kManoThreads) sHP[i / ncomp][i % ncomp] = hand_pose[(int64_t)b0 * ncomp + i];
+    for (int i = tid; i < ncomp * 45; i += kManoThreads) sComps[i] = comps[i];
+    if (tid < kJ * 3) sJ[tid] = joints[tid];
+    if (tid < kJ) sPar[tid] = parents[tid];
+    __syncthreads();
 
     // ---- A: full pose and Rodrigues, one thread per (hand, joint)   (lbs.py:167-198)
-    if (tid < kHB * kJ) {
+    if (tid < kMH * kJ) {
         const int hnd = tid / kJ, j = tid % kJ;
+        if (j == 0) sPF[hnd][kPF] = 0.f;
         if (hnd < nh) {
             const int b = b0 + hnd;
             float rv[3];
@@ -51,7 +80,7 @@ __global__ __launch_bounds__(kManoThreads, 2) void mano_lbs_kernel(
                 } else {
                     const int col = 3 * (j - 1) + c;
                     v = 0.f;
-                    for (int i = 0; i < ncomp; ++i) v = __builtin_fmaf(hand_pose[b * ncomp + i], comps[i * 45 + col], v);
+                    for (int i = 0; i < ncomp; ++i) v = __builtin_fmaf(sHP[hnd][i], sComps[i * 45 + col], v);
                 }
                 v += pose_mean[3 * j + c];
                 rv[c] = v;
@@ -79,132 +108,166 @@ __global__ __launch_bounds__(kManoThreads, 2) void mano_lbs_kernel(
 #pragma unroll
                 for (int c = 0; c < 3; ++c) sTr[hnd][c] = transl ? transl[b * 3 + c] : 0.f;
             }
+        } else if (j > 0) {   // hands past the end of the batch: finite operands for the matrix product
+#pragma unroll
+            for (int e = 0; e < 9; ++e) sPF[hnd][(j - 1) * 9 + e] = 0.f;
         }
     }
     __syncthreads();
 
-    // ---- B: kinematic chain, one thread per hand   (lbs.py:214-265)
-    if (tid < nh) {
-        const int hnd = tid;
+    // ---- B: kinematic chain, one thread per (hand, row of the 3x4 transform)   (lbs.py:214-265)
+    if (tid < 3 * nh) {
+        const int hnd = tid / 3, a = tid % 3;
         for (int i = 0; i < kJ; ++i) {
-            const int par = parents[i];
+            const int par = sPar[i];
             float t[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) t[c] = (i == 0) ? joints[c] : joints[i * 3 + c] - joints[par * 3 + c];
-            float T[12];
+            for (int c = 0; c < 3; ++c) t[c] = (i == 0) ? sJ[c] : sJ[i * 3 + c] - sJ[par * 3 + c];
+            float T[4];
             if (i == 0) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) T[a * 4 + c] = sR[hnd][0][a * 3 + c];
-                    T[a * 4 + 3] = t[a];
-                }
+                for (int c = 0; c < 3; ++c) T[c] = sR[hnd][0][a * 3 + c];
+                T[3] = t[a];
             } else {
-                const float* P = sT[hnd][par];
+                const float* P = &sT[hnd][par][a * 4];   // written by this very thread in an earlier step
+                const float p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float v = P[a * 4 + 0] * sR[hnd][i][0 * 3 + c];
-                        v = __builtin_fmaf(P[a * 4 + 1], sR[hnd][i][1 * 3 + c], v);
-                        v = __builtin_fmaf(P[a * 4 + 2], sR[hnd][i][2 * 3 + c], v);
-                        T[a * 4 + c] = v;
-                    }
-                    float v = P[a * 4 + 0] * t[0];
-                    v = __builtin_fmaf(P[a * 4 + 1], t[1], v);
-                    v = __builtin_fmaf(P[a * 4 + 2], t[2], v);
-                    T[a * 4 + 3] = v + P[a * 4 + 3];
+                for (int c = 0; c < 3; ++c) {
+                    float v = p0 * sR[hnd][i][0 * 3 + c];
+                    v = __builtin_fmaf(p1, sR[hnd][i][1 * 3 + c], v);
+                    v = __builtin_fmaf(p2, sR[hnd][i][2 * 3 + c], v);
+                    T[c] = v;
                 }
+                float v = p0 * t[0];
+                v = __builtin_fmaf(p1, t[1], v);
+                v = __builtin_fmaf(p2, t[2], v);
+                T[3] = v + p3;
             }
 #pragma unroll
-            for (int e = 0; e < 12; ++e) sT[hnd][i][e] = T[e];
+            for (int e = 0; e < 4; ++e) sT[hnd][i][a * 4 + e] = T[e];
             // A = T - pad(T * [J;0])   (lbs.py:260-263)
-            const float jx = joints[i * 3 + 0], jy = joints[i * 3 + 1], jz = joints[i * 3 + 2];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float v = T[a * 4 + 0] * jx;
-                v = __builtin_fmaf(T[a * 4 + 1], jy, v);
-                v = __builtin_fmaf(T[a * 4 + 2], jz, v);
-                sA[hnd][i][a * 4 + 0] = T[a * 4 + 0];
-                sA[hnd][i][a * 4 + 1] = T[a * 4 + 1];
-                sA[hnd][i][a * 4 + 2] = T[a * 4 + 2];
-                sA[hnd][i][a * 4 + 3] = T[a * 4 + 3] - v;
-            }
-            if (joints_out) {
-                const int b = b0 + hnd;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) joints_out[(b * kJ + i) * 3 + c] = T[c * 4 + 3] + sTr[hnd][c];
-            }
+            float v = T[0] * sJ[i * 3 + 0];
+            v = __builtin_fmaf(T[1], sJ[i * 3 + 1], v);
+            v = __builtin_fmaf(T[2], sJ[i * 3 + 2], v);
+            sA(hnd, i)[a * 4 + 0] = T[0];
+            sA(hnd, i)[a * 4 + 1] = T[1];
+            sA(hnd, i)[a * 4 + 2] = T[2];
+            sA(hnd, i)[a * 4 + 3] = T[3] - v;
+            if (joints_out) joints_out[((b0 + hnd) * kJ + i) * 3 + a] = T[3] + sTr[hnd][a];
         }
     }
     __syncthreads();
 
-    // ---- C: per vertex: pose blend shapes, then skinning   (lbs.py:90-118)
-    for (int v = tid; v < V; v += kManoThreads) {
-        {
-            float vp[kHB][3];
+    // ---- C: per group of 16 vertices: pose blend shapes on the matrix cores, then skinning   (lbs.py:90-118)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane & 15, q = lane >> 4;
+    float bfrag[kKS];                                   // B operand: pose feature 4s + q of hand h
 #pragma unroll
-            for (int hnd = 0; hnd < kHB; ++hnd) { vp[hnd][0] = 0.f; vp[hnd][1] = 0.f; vp[hnd][2] = 0.f; }
-            const float* pd = posedirs + 3 * v;
-            const int stride = 3 * V;
-#pragma unroll 3
-            for (int p = 0; p < kPF; ++p) {
-                const float d0 = pd[(int64_t)p * stride + 0], d1 = pd[(int64_t)p * stride + 1], d2 = pd[(int64_t)p * stride + 2];
+    for (int s = 0; s < kKS; ++s) bfrag[s] = sPF[h][4 * s + q];
+    const int n_groups = (V + 15) / 16;
+    const int64_t prow = 3 * (int64_t)V;
+    // A operand of group g: vertex 16g + (lane & 15), pose feature 4s + q; tile t = coordinate axis t.  All 34 k-steps
+    // of a group are fetched at once (12 B per lane each) and the next group's are requested before this group's
+    // skinning, so the L2 latency is paid under vector work.  Feature 135 does not exist: its B operand is zero, the
+    // load is clamped to feature 134; vertices past the end are clamped too and never stored.
+    f32x3 afrag[kKS];
+    auto load_group = [&](int g) {
+        int vr = 16 * g + h;
+        if (vr >= V) vr = V - 1;
+        const float* pd = posedirs + 3 * (int64_t)vr;
 #pragma unroll
-                for (int hnd = 0; hnd < kHB; ++hnd) {
-                    const float f = sPF[hnd][p];
-                    vp[hnd][0] = __builtin_fmaf(f, d0, vp[hnd][0]);
-                    vp[hnd][1] = __builtin_fmaf(f, d1, vp[hnd][1]);
-                    vp[hnd][2] = __builtin_fmaf(f, d2, vp[hnd][2]);
-                }
-            }
-            const float vx = v_shaped[v * 3 + 0], vy = v_shaped[v * 3 + 1], vz = v_shaped[v * 3 + 2];
+        for (int s = 0; s < kKS; ++s) {
+            const int k = (4 * s + q) < kPF ? (4 * s + q) : kPF - 1;
+            afrag[s] = *reinterpret_cast<const f32x3*>(pd + k * prow);
+        }
+    };
+    // the skinning slots of this lane's four vertices, requested before the group's MFMAs and used after them
+    constexpr int NSLOT = TABLE ? kSkinW : kJ;
+    f32x4 sw[4][NSLOT / 4];
+    uint2 sj[4];                                        // eight joint ids of a vertex, one byte each
+    f32x3 vs[4];                                        // rest position of the four vertices
+    auto load_skin = [&](int g) {
 #pragma unroll
-            for (int hnd = 0; hnd < kHB; ++hnd) {  // v_posed = pose_offsets + v_shaped  (lbs.py:101)
-                sVP[hnd][0][tid] = vp[hnd][0] + vx;
-                sVP[hnd][1][tid] = vp[hnd][1] + vy;
-                sVP[hnd][2][tid] = vp[hnd][2] + vz;
+        for (int i = 0; i < 4; ++i) {
+            int v = 16 * g + 4 * q + i;
+            if (v >= V) v = V - 1;
+#pragma unroll
+            for (int c = 0; c < NSLOT / 4; ++c)
+                sw[i][c] = *reinterpret_cast<const f32x4*>((TABLE ? skin_weights : weights) + (int64_t)v * NSLOT + 4 * c);
+            if (TABLE) sj[i] = *reinterpret_cast<const uint2*>(skin_joints + (int64_t)v * kSkinW);
+            vs[i] = *reinterpret_cast<const f32x3*>(v_shaped + (int64_t)v * 3);
+        }
+    };
+    if (wave < n_groups) load_group(wave);
+    for (int g = wave; g < n_groups; g += kManoThreads / 64) {
+        const int v0 = 16 * g;
+        if (TABLE) load_skin(g);
+        f32x4 acc[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < kKS; ++s) {
+            const float bf = bfrag[s];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].x, bf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].y, bf, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].z, bf, acc[2], 0, 0, 0);
+        }
+        if (g + kManoThreads / 64 < n_groups) load_group(g + kManoThreads / 64);
+        if (!TABLE) load_skin(g);
+        // this lane: hand h, vertices v0 + 4q + i (register i of the three tiles)
+        const int64_t hb = (int64_t)(b0 + (h < nh ? h : 0)) * V;
+        // Table slots are non-zero first: the number of slots any lane of the wave still needs bounds the loop.
+        int n_slots = NSLOT;
+        if (TABLE) {
+            n_slots = 0;
+#pragma unroll
+            for (int e = 0; e < kSkinW; ++e) {
+                const bool any = sw[0][e / 4][e % 4] != 0.f || sw[1][e / 4][e % 4] != 0.f || sw[2][e / 4][e % 4] != 0.f ||
+                                 sw[3][e / 4][e % 4] != 0.f;
+                if (__ballot(any) != 0) n_slots = e + 1;
             }
         }
-        float w[kJ];
+        if (h >= nh) continue;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(weights + v * kJ + 4 * q);
-            w[4 * q + 0] = t[0]; w[4 * q + 1] = t[1]; w[4 * q + 2] = t[2]; w[4 * q + 3] = t[3];
-        }
-#pragma unroll 1
-        for (int hnd = 0; hnd < nh; ++hnd) {
-            const float px = sVP[hnd][0][tid], py = sVP[hnd][1][tid], pz = sVP[hnd][2][tid];
+        for (int i = 0; i < 4; ++i) {
+            const int v = v0 + 4 * q + i;
+            if (v >= V) break;
+            // T = sum_j w_j A_j over the slots (joints ascending)
             float T[12];
 #pragma unroll
             for (int e = 0; e < 12; ++e) T[e] = 0.f;
-            // T = sum_j w_j A_j: zero weights (13 of 16 per vertex on average) contribute exact
-            // zeros, as in the reference's dense product
 #pragma unroll
-            for (int j = 0; j < kJ; ++j) {
-                const f32x4 A0 = *reinterpret_cast<const f32x4*>(&sA[hnd][j][0]);
-                const f32x4 A1 = *reinterpret_cast<const f32x4*>(&sA[hnd][j][4]);
-                const f32x4 A2 = *reinterpret_cast<const f32x4*>(&sA[hnd][j][8]);
+            for (int e = 0; e < NSLOT; ++e) {
+                if (e >= n_slots) break;
+                const int j = TABLE ? (int)(((e < 4 ? sj[i].x : sj[i].y) >> (8 * (e & 3))) & 15u) : e;
+                const float w = sw[i][e / 4][e % 4];
+                const f32x4 A0 = *reinterpret_cast<const f32x4*>(sA(h, j));
+                const f32x4 A1 = *reinterpret_cast<const f32x4*>(sA(h, j) + 4);
+                const f32x4 A2 = *reinterpret_cast<const f32x4*>(sA(h, j) + 8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    T[e] = __builtin_fmaf(w[j], A0[e], T[e]);
-                    T[4 + e] = __builtin_fmaf(w[j], A1[e], T[4 + e]);
-                    T[8 + e] = __builtin_fmaf(w[j], A2[e], T[8 + e]);
+                for (int c = 0; c < 4; ++c) {
+                    T[c] = __builtin_fmaf(w, A0[c], T[c]);
+                    T[4 + c] = __builtin_fmaf(w, A1[c], T[4 + c]);
+                    T[8 + c] = __builtin_fmaf(w, A2[c], T[8 + c]);
                 }
             }
-            float* dst = verts_out + ((int64_t)(b0 + hnd) * V + v) * 3;
+            // v_posed = pose_offsets + v_shaped  (lbs.py:101)
+            const float px = acc[0][i] + vs[i].x, py = acc[1][i] + vs[i].y, pz = acc[2][i] + vs[i].z;
             if (v_posed_out) {   // kept for dvq_mano_lbs_backward
-                float* vpd = v_posed_out + ((int64_t)(b0 + hnd) * V + v) * 3;
-                vpd[0] = px; vpd[1] = py; vpd[2] = pz;
+                f32x3 o = {px, py, pz};
+                *reinterpret_cast<f32x3*>(v_posed_out + (hb + v) * 3) = o;
             }
+            f32x3 o;
+            float* dst = &o.x;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 float r = T[a * 4 + 0] * px;
                 r = __builtin_fmaf(T[a * 4 + 1], py, r);
                 r = __builtin_fmaf(T[a * 4 + 2], pz, r);
                 r = r + T[a * 4 + 3];
-                dst[a] = r + sTr[hnd][a];
+                dst[a] = r + sTr[h][a];
             }
+            *reinterpret_cast<f32x3*>(verts_out + (hb + v) * 3) = o;
         }
     }
 }
@@ -222,10 +285,18 @@ extern "C" int dvq_mano_lbs(const float* global_orient, const float* hand_pose, 
     if (m->n_verts < 1 || m->n_comps < 1 || m->n_comps > 45) return fail(DVQ_EINVAL, "mano: bad n_verts/n_comps (%d, %d)", m->n_verts, m->n_comps);
     if (!m->v_shaped || !m->joints || !m->posedirs || !m->lbs_weights || !m->components || !m->pose_mean || !m->parents)
         return fail(DVQ_EINVAL, "mano: null constant table");
+    const bool table = m->skin_joints != nullptr;
+    if (table && (!m->skin_weights || m->skin_width != kSkinW || ((uintptr_t)m->skin_joints & 7) || ((uintptr_t)m->skin_weights & 15)))
+        return fail(DVQ_EINVAL, "mano: the skinning table needs skin_weights, skin_width == %d and aligned arrays (joints 8, weights 16 bytes)", kSkinW);
     if (((uintptr_t)m->lbs_weights & 15) != 0) return fail(DVQ_EINVAL, "mano: lbs_weights must be 16-byte aligned");
-    const int grid = (B + kHB - 1) / kHB;
-    hipLaunchKernelGGL(mano_lbs_kernel, dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
-                       m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
-                       m->parents, verts_out, joints_out, full_pose_out, v_posed_out);
+    const int grid = (B + kMH - 1) / kMH;
+    if (table)
+        hipLaunchKernelGGL(mano_lbs_kernel<true>, dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
+                           m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
+                           m->parents, m->skin_joints, m->skin_weights, verts_out, joints_out, full_pose_out, v_posed_out);
+    else
+        hipLaunchKernelGGL(mano_lbs_kernel<false>, dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
+                           m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
+                           m->parents, nullptr, nullptr, verts_out, joints_out, full_pose_out, v_posed_out);
     return check_launch("mano_lbs");
 }

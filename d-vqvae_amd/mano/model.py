@@ -175,13 +175,22 @@ class MANO(nn.Module):
                     v_shaped = self.v_template.clone()
                 joints = torch.einsum('ik,ji->jk', v_shaped, self.J_regressor)
                 comps = self.hand_components if self.use_pca else torch.eye(45, device=dev)
+                # the non-zero skinning weights of every vertex (1-6 of 16), joints ascending, zero-padded to one width
+                nz = self.lbs_weights != 0
+                width = 8                                 # slots of the kernel's table; denser models take the dense path
+                has_table = int(nz.sum(1).max()) <= width
+                order = torch.argsort((~nz).to(torch.int8), dim=1, stable=True)[:, :width]
                 keep = dict(v_shaped=v_shaped.contiguous(), joints=joints.contiguous(),
                             posedirs=self.posedirs.contiguous(), weights=self.lbs_weights.contiguous(),
                             comps=comps.contiguous().float(), pose_mean=self.pose_mean.contiguous(),
-                            parents=self.parents.to(torch.int32).contiguous())
+                            parents=self.parents.to(torch.int32).contiguous(),
+                            skin_joints=order.to(torch.uint8).contiguous(),
+                            skin_weights=torch.gather(self.lbs_weights, 1, order).contiguous())
             c = DvqManoConsts(int(v_shaped.shape[0]), int(comps.shape[0]), keep['v_shaped'].data_ptr(),
                               keep['joints'].data_ptr(), keep['posedirs'].data_ptr(), keep['weights'].data_ptr(),
-                              keep['comps'].data_ptr(), keep['pose_mean'].data_ptr(), keep['parents'].data_ptr())
+                              keep['comps'].data_ptr(), keep['pose_mean'].data_ptr(), keep['parents'].data_ptr(),
+                              keep['skin_joints'].data_ptr() if has_table else None,
+                              keep['skin_weights'].data_ptr() if has_table else None, width)
             self._consts = (c, keep)
             self._consts_key = key
         return self._consts[0]

@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 107   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 108   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -184,6 +184,12 @@ typedef struct {
     const float* components;  /* [n_comps,45]                             */
     const float* pose_mean;   /* [48]                                     */
     const int*   parents;     /* [16], parents[0] = -1                    */
+    /* optional table of the non-zero skinning weights (lbs_weights has 1-6 per vertex): vertex v, slot e ->
+     * joint skin_joints[v*skin_width + e] with weight skin_weights[v*skin_width + e], the vertex's non-zero joints in
+     * ascending order, remaining slots weight 0 (any valid joint).  NULL: the forward pass reads all 16 dense weights. */
+    const unsigned char* skin_joints;
+    const float* skin_weights;
+    int skin_width;           /* 8 (vertices with more non-zero weights: leave the table NULL) */
 } DvqManoConsts;
 
 int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float* transl, int B,

@@ -45,6 +45,23 @@ def test_mano_vs_reference_golden_on_real_grasp_parameters():
     assert ev <= 1e-5 and ej <= 1e-5
 
 
+def test_mano_skinning_table_equals_dense_weights():
+    """The kernel gathers a vertex's transform from a table of its non-zero skinning weights (joints ascending); with
+    the table absent it sums all 16 dense weights as the reference does.  The skipped terms are exact zeros: same bits."""
+    import ctypes
+    from dvq_hip._lib import DvqManoConsts
+    rh = make_mano(1)
+    go, hp, tr = (t.to(DEV) for t in synth.mano_inputs(37, seed=4))
+    c = rh._device_consts()
+    assert c.skin_joints is not None and c.skin_width == 8
+    dense = DvqManoConsts()
+    ctypes.memmove(ctypes.byref(dense), ctypes.byref(c), ctypes.sizeof(c))
+    dense.skin_joints, dense.skin_weights = None, None
+    a = ops.mano_lbs(go, hp, tr, c, 778, want_v_posed=True)
+    b = ops.mano_lbs(go, hp, tr, dense, 778, want_v_posed=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+
+
 @pytest.mark.parametrize("B", [1, 3, 8, 9, 67])
 def test_mano_batches_vs_oracle(B):
     rh = make_mano(1)
