@@ -28,6 +28,9 @@ from dvq_hip import ops, parallel, synth  # noqa: E402
 from dvq_hip.pipeline import GraspGenerator  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X
+PMC_TRAFFIC_BYTES = 2.173e8                     # encoder trunk, 4096 x 3000 x C4 bf16: FETCH_SIZE x 2 + WRITE_SIZE per launch
+PEAK_HBM_GBS = 8000.0                           # HBM3E spec; a bare 16-B-per-lane read of 0.5 GB reaches 5.0-5.4 TB/s here
+PEAK_L2_LDS_GBS = 17500.0                       # L2 -> LDS gather rate the part sustains (16.8-18.8 TB/s measured)
 FLOP_PER_POINT = {3: 2 * (3 * 64 + 64 * 128 + 128 * 1024), 4: 2 * (4 * 64 + 64 * 128 + 128 * 1024)}
 
 
@@ -65,18 +68,41 @@ def kernel_stats(name_prefix):
     return best
 
 
+def near_ties(z, E, idx, ulps=4.0):
+    """On a sample of rows (z, E as the kernel saw them, widened to fp64): how many have their two nearest codes closer
+    than `ulps` fp32 ulps of |z|^2 + max|E|^2 (where the reference's own fp32 rounding decides the winner), and how
+    many of the kernel's choices are not the exact fp64 nearest code / not even within that tolerance of it."""
+    z64, E64 = z.double(), E.double()
+    d = (z64 * z64).sum(1, keepdim=True) + (E64 * E64).sum(1) - 2.0 * z64 @ E64.t()
+    top = torch.topk(d, 2, dim=1, largest=False)
+    scale = (z.float() ** 2).sum(1) + (E.float() ** 2).sum(1).max()
+    tau = ulps * torch.ldexp(torch.ones_like(scale), torch.floor(torch.log2(scale)).to(torch.int32) - 23).double()
+    chosen = d.gather(1, idx.view(-1, 1))[:, 0]
+    return {"rows": int(z.shape[0]), "near_tie_rows": int((top.values[:, 1] - top.values[:, 0] <= tau).sum()),
+            "differs_from_exact_argmin": int((idx != top.indices[:, 0]).sum()),
+            "outside_tolerance": int((chosen - top.values[:, 0] > tau).sum())}
+
+
 def vq_microbench(device, n_rows=1 << 20, iters=5):
-    """Isolated nearest-codebook search: 1 Mi latents, reference codebook shapes (128 x 256 and 128 x 1024) + K sweep."""
+    """Isolated nearest-codebook search: 1 Mi latents, reference codebook shapes (128 x 256 and 128 x 1024) + K sweep on
+    well-separated latents (distribution B: z = a code + noise), and the reference's own initialisation (distribution A:
+    E ~ U(-1/K, 1/K), DVQ-VAE/network/vqvae/quantizer.py:27; z ~ N(0, 0.01^2)) at its codebook shape, with the
+    near-tie count of a 4096-row sample."""
     out = []
     for dtype, name in ((torch.bfloat16, "bf16"), (torch.float32, "fp32")):
-        for K, D in ((128, 256), (512, 256), (2048, 256), (8192, 256), (128, 1024)):
+        for K, D, dist in ((128, 256, "B"), (512, 256, "B"), (1024, 256, "B"), (2048, 256, "B"), (8192, 256, "B"), (128, 1024, "B"),
+                           (128, 256, "A")):
             n = n_rows if D == 256 else n_rows // 4     # the 1024-wide object codebook: same bytes of latents
             g = torch.Generator(device).manual_seed(K)
-            E = torch.randn(K, D, device=device, generator=g)
-            j = torch.randint(0, K, (n,), device=device, generator=g)
-            z = (E[j] + 0.3 * torch.randn(n, D, device=device, generator=g)).to(dtype)
+            if dist == "B":
+                E = torch.randn(K, D, device=device, generator=g)
+                j = torch.randint(0, K, (n,), device=device, generator=g)
+                z = (E[j] + 0.3 * torch.randn(n, D, device=device, generator=g)).to(dtype)
+                del j
+            else:
+                E = (torch.rand(K, D, device=device, generator=g) * 2 - 1) / K
+                z = (0.01 * torch.randn(n, D, device=device, generator=g)).to(dtype)
             E = E.to(dtype)
-            del j
             ws = ops.vq_prepare(E)
             ops.vq_argmin(z, E, want_zq=False, prepared=ws)
             torch.cuda.synchronize(device)
@@ -89,16 +115,59 @@ def vq_microbench(device, n_rows=1 << 20, iters=5):
             ms = e0.elapsed_time(e1) / iters
             flops = 2.0 * n * K * D
             nbytes = n * D * z.element_size() + K * D * z.element_size() + 8 * n
-            out.append({"K": K, "D": D, "dtype": name, "n": n, "ms": round(ms, 4),
-                        "tflops": round(flops / ms / 1e9, 1),
-                        "frac_mfma_peak": round(flops / ms / 1e9 / PEAK_TFLOPS[name], 4),
-                        "hbm_gbs": round(nbytes / ms / 1e6, 1),
-                        "mlatents_per_s": round(n / ms / 1e3, 1)})
+            rec = {"K": K, "D": D, "dtype": name, "dist": dist, "n": n, "ms": round(ms, 4),
+                   "tflops": round(flops / ms / 1e9, 1),
+                   "frac_mfma_peak": round(flops / ms / 1e9 / PEAK_TFLOPS[name], 4),
+                   "hbm_gbs": round(nbytes / ms / 1e6, 1), "frac_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4),
+                   "mlatents_per_s": round(n / ms / 1e3, 1)}
+            if D == 256 and K <= 512:
+                idx, _ = ops.vq_argmin(z, E, want_zq=False, prepared=ws)
+                rec["near_ties_4096_row_sample"] = near_ties(z[:4096], E, idx[:4096])
+            out.append(rec)
             del z, E, ws
     return out
 
 
-def cpu_baseline(with_prior, budget_s=12.0, batch=16):
+def prior_roofline(gen, B, device, iters=20):
+    """The prior's dominant launch -- the horizontal-stack gate product of one layer and cell (bf16: [B,2048] x
+    [2048,1024] over three taps) -- launched alone with HIP events around it.  It is bound by operand delivery from L2
+    into LDS: every 128-row x 64-column workgroup tile pulls its own weight and activation units."""
+    pr = gen.model.GatedPixelCNN
+    if pr.compute_dtype != torch.bfloat16 or B < 256:
+        return None
+    layers, _ = pr._prepared_hip()
+    bufs = pr._act_buffers(B, 3, 3, device)
+    t, d = layers[1], pr.dim
+    kb = d // 32
+    taps = [(bufs["XH"][0][1], t.horiz[0], kb), (bufs["XH"][1][1], t.horiz[-1], kb), (bufs["HV"][1][1], t.v2h, 2 * kb)]
+    job = ops.prior_job(taps, t.horiz_bias, cond=t.cond, label=bufs["label"], out_packed=bufs["OUT"])
+    run = lambda: ops.prior_gemm([job], B, 2 * d, ops.PRIOR_GATE, False, bufs["emb"])
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / iters
+    M, N, K = B, 2 * d, 4 * d
+    gy = (M + 127) // 128                                  # row tiles of 128 samples
+    no = 4 if (N // 128) * gy >= 512 else 2                # column tile of 128 or 64 features (dvq_prior_gemm's rule)
+    gx = N // (32 * no)
+    l2_bytes = 2.0 * K * (gy * N + gx * M)                 # every row tile reads the weights, every column tile the activations
+    flops = 2.0 * M * N * K
+    ach = l2_bytes / ms / 1e6
+    return {"bound": "l2", "kernel": f"prior_gemm gate product [M={M}, N={N}, K={K}], tile 128x{32 * no}",
+            "achieved": round(ach, 1), "peak": PEAK_L2_LDS_GBS, "unit": "GB/s", "frac": round(ach / PEAK_L2_LDS_GBS, 4),
+            "traffic": None, "avg_launch_ms": round(ms, 5), "launches_timed": iters, "l2_to_lds_bytes_per_launch": l2_bytes,
+            "tflops": round(flops / ms / 1e9, 1), "frac_mfma_peak": round(flops / ms / 1e9 / PEAK_TFLOPS["bf16"], 4),
+            "note": "launched back to back outside the replayed graph; 135 such launches + 135 residual 1x1 products + "
+                    "45 vertical-row launches make one grid batch"}
+
+
+def cpu_baseline(with_prior, reps=10, batch=16):
     """The CPU oracle (op-for-op restatement of the reference's PyTorch path) on this box's
     host cores, on a bounded sample of the same workload."""
     from oracle import dvq_oracle as O
@@ -108,14 +177,17 @@ def cpu_baseline(with_prior, budget_s=12.0, batch=16):
     forced = None if with_prior else torch.randint(0, 128, (batch, 3, 3), generator=torch.Generator().manual_seed(0))
     gen = torch.Generator().manual_seed(0)
     with torch.no_grad():
-        O.generate_grasps(sd, objs[:2], x_tilde=None if forced is None else forced[:2], generator=gen)   # warm-up
-        done, t0 = 0, time.perf_counter()
-        while True:
+        for _ in range(2):                                      # warm-up
+            O.generate_grasps(sd, objs[:2], x_tilde=None if forced is None else forced[:2], generator=gen)
+        times = []
+        t_all = time.perf_counter()
+        while len(times) < reps and (len(times) < 3 or time.perf_counter() - t_all < 25.0):
+            t0 = time.perf_counter()
             O.generate_grasps(sd, objs, x_tilde=forced, generator=gen)
-            done += batch
-            el = time.perf_counter() - t0
-            if el >= budget_s or el + el / (done / batch) > 30.0:
-                break
+            times.append(time.perf_counter() - t0)
+        el = time.perf_counter() - t_all
+        done = batch * len(times)
+        med = sorted(times)[len(times) // 2]
         # the reference's literal call pattern: one object per gen() call (a few seconds' worth)
         n1, t1 = 0, time.perf_counter()
         while time.perf_counter() - t1 < 4.0:
@@ -132,10 +204,11 @@ def cpu_baseline(with_prior, budget_s=12.0, batch=16):
                     break
     except OSError:
         pass
-    return {"value": round(done / el, 3), "unit": "grasps/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(batch / med, 3), "unit": "grasps/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu_model": cpu_model, "value_one_object_per_call": round(n1 / el1, 3),
-            "sample": f"{done} grasps in batches of {batch} x 3000-pt clouds, fp32 torch CPU ops, "
-                      f"prior {'sampled' if with_prior else 'teacher-forced'}, {el:.1f} s; then {n1} single-object calls, {el1:.1f} s"}
+            "sample": f"median of {len(times)} timed batches of {batch} x 3000-pt clouds ({done} grasps, {el:.1f} s) after 2 warm-up "
+                      f"calls, fp32 torch CPU ops, prior {'sampled' if with_prior else 'teacher-forced'}; then {n1} "
+                      f"single-object calls, {el1:.1f} s"}
 
 
 def tta_bench(gen, obj, first_id, device, iters=30):
@@ -267,14 +340,14 @@ def main():
             flops = float(kb) * kn * FLOP_PER_POINT[kc]
             ach = flops / avg_ms / 1e9
             # HBM bytes per launch from the FETCH_SIZE (x2, the gfx950 correction for 16-B-per-lane streams) and
-            # WRITE_SIZE counters, collected in separate rocprofv3 --pmc passes of this workload
-            # (profiles/r1g_pmc_fetch_write.txt); only valid for the configuration it was measured on
-            traffic = 2.173e8 if (kb, kc, kn, args.dtype) == (4096, 4, 3000, "bf16") else None
+            # WRITE_SIZE counters: NOT measured by this run -- a constant from separate rocprofv3 --pmc passes over the
+            # same kernel and shape (profiles/r2c_pmc_fetch_write.txt); only valid for that configuration
+            traffic = PMC_TRAFFIC_BYTES if (kb, kc, kn, args.dtype) == (4096, 4, 3000, "bf16") else None
             result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1),
                                   "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                   "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
-                                  "traffic_note": "HBM bytes per launch, PMC passes in profiles/r1g_pmc_fetch_write.txt; "
-                                                  "algorithmic bytes 2.134e8",
+                                  "traffic_note": "HBM bytes per launch from separate PMC passes (profiles/r2c_pmc_fetch_write.txt), "
+                                                  "not from this run; algorithmic bytes 2.134e8",
                                   "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
                                   # half of the launches share the GPU with the prior running on the other stream; the
                                   # launches that had it to themselves (first object encoder) for comparison
@@ -292,9 +365,15 @@ def main():
         import dvq_hip
         dvq_hip.set_compute_dtype(gen.model, odt)
         el = timed_steps(lambda: step("forced"), 2, 1, device, barrier)
-        variants[f"{'fp32' if args.dtype == 'bf16' else 'bf16'}_prior_forced"] = round(B * 2 / el, 1)
+        oname = 'fp32' if args.dtype == 'bf16' else 'bf16'
+        variants[f"{oname}_prior_forced"] = round(B * 2 / el, 1)
+        el = timed_steps(lambda: step("sampled"), 2, 1, device, barrier)
+        variants[f"{oname}_prior_sampled"] = round(B * 2 / el, 1)
         dvq_hip.set_compute_dtype(gen.model, tdtype)
         result["variants_grasps_per_s"] = variants
+        pr = prior_roofline(gen, B, device)
+        if pr is not None:
+            result["roofline_prior"] = pr
         result["tta_refinement"] = tta_bench(gen, obj, first_id, device)
         del obj
         torch.cuda.empty_cache()
