@@ -265,6 +265,7 @@ __device__ __forceinline__ void pn_body(
             DVQ_PN_TILE(0) DVQ_PN_TILE(1) DVQ_PN_TILE(2) DVQ_PN_TILE(3)
 #undef DVQ_PN_TILE
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own direct-to-LDS copies landed before they are published
         __syncthreads();  // stage 0 has landed (the barrier drains the direct-to-LDS loads)
 
         // ---- conv3 + max, one LDS stage of output-channel tiles at a time
@@ -313,6 +314,7 @@ __device__ __forceinline__ void pn_body(
 #pragma unroll 1
                 for (int cc = 0; cc < Cfg::CPS; ++cc) conv3_tile(std::integral_constant<int, 1>{}, cc);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own direct-to-LDS copies landed before they are published
             __syncthreads();  // next stage landed; this buffer is free for the stage after
         }
     }
@@ -515,6 +517,7 @@ __device__ __forceinline__ void pn16_body(
     }
         DVQ_PN_TILE16(0) DVQ_PN_TILE16(1) DVQ_PN_TILE16(2) DVQ_PN_TILE16(3)
 #undef DVQ_PN_TILE16
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own direct-to-LDS copies landed before they are published
         __syncthreads();  // stage 0 has landed
 
 #pragma unroll 1
@@ -562,6 +565,7 @@ __device__ __forceinline__ void pn16_body(
             else if (nv == 3) conv3_stage(std::integral_constant<int, 3>{});
             else if (nv == 2) conv3_stage(std::integral_constant<int, 2>{});
             else if (nv == 1) conv3_stage(std::integral_constant<int, 1>{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own direct-to-LDS copies landed before they are published
             __syncthreads();
         }
     }

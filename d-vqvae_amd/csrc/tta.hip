@@ -42,7 +42,7 @@ constexpr int kCgWaves = kCgThreads / 64;
 // Vertices are searched in `order`: the n_contact vertices of the contact set first, then the others.
 // The nearest contact-set vertex is then simply the running minimum at the end of the first group, and
 // every (point, vertex) pair costs three packed subtract/multiply-add pairs and one compare-select, not two.
-// Exact distance ties resolve to the vertex met first in that order.
+// Exact distance ties resolve to the lowest vertex id (both parts of `order` must list their vertices ascending).
 __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
     const float* __restrict__ obj, int64_t sb, int64_t sc, int64_t sp, int N, const float* __restrict__ verts, int V, int nC,
     const int* __restrict__ faces, const int* __restrict__ vf_ptr, const int* __restrict__ vf,
@@ -150,18 +150,30 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
         int ci[kTtaPts];
 #pragma unroll
         for (int q = 0; q < kTtaPts; ++q) { cbest[q] = best[q >> 1][q & 1]; ci[q] = resolve(q, bi[q], nC); bi[q] = ci[q]; }
-        // the running best now names an exact vertex; mark it so that a later group start is distinguishable
-        int exact[kTtaPts];
+        // the other vertices are scanned from scratch; the nearer of the two winners is the nearest vertex, and at
+        // exactly equal distances the one with the lower vertex id (inside either part the order is ascending, so
+        // the first met is the lowest): ties go to the lowest index, as a plain scan over all vertices would give
 #pragma unroll
-        for (int q = 0; q < kTtaPts; ++q) { exact[q] = bi[q]; bi[q] = -1; }
+        for (int q = 0; q < kTtaPts; ++q) { best[q >> 1][q & 1] = inf; bi[q] = nC; }
         scan(nC, V);
+        float bdist[kTtaPts];
 #pragma unroll
-        for (int q = 0; q < kTtaPts; ++q) bi[q] = bi[q] < 0 ? exact[q] : resolve(q, bi[q], V);
+        for (int q = 0; q < kTtaPts; ++q) {
+            bdist[q] = cbest[q];
+            int win = ci[q];
+            if (V > nC) {
+                const int other = resolve(q, bi[q], V);
+                const float d2 = best[q >> 1][q & 1];
+                const bool lower = __float_as_int(hv[other][3]) < __float_as_int(hv[ci[q]][3]);
+                if (d2 < cbest[q] || (d2 == cbest[q] && lower)) { win = other; bdist[q] = d2; }
+            }
+            bi[q] = win;
+        }
 #pragma unroll
         for (int q = 0; q < kTtaPts; ++q) {
             const int i = i0 + q * kCgThreads;
             if (i >= N) continue;
-            const float ox = px[q >> 1][q & 1], oy = py[q >> 1][q & 1], oz = pz[q >> 1][q & 1], bd = best[q >> 1][q & 1];
+            const float ox = px[q >> 1][q & 1], oy = py[q >> 1][q & 1], oz = pz[q >> 1][q & 1], bd = bdist[q];
             const f32x4 h = hv[bi[q]], n = hn[bi[q]];
             const float dot = (h[0] - ox) * n[0] + (h[1] - oy) * n[1] + (h[2] - oz) * n[2];
             const long long fx = __float2ll_rn(ox * kFix), fy = __float2ll_rn(oy * kFix), fz = __float2ll_rn(oz * kFix);

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_kernel(VqBatch vb, 
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { best[nb] = -__builtin_inff(); bidx[nb] = 0; }
         if (!resident) {
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's direct-to-LDS copies have landed ...
+            __syncthreads();                                    // ... and so have everyone else's
             resident = (n_stages == 1);
         }
         for (int st = 0; st < n_stages; ++st) {
@@ -404,7 +405,10 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_kernel(VqBatch vb, 
                         }
                 }
             }
-            if (n_stages > 1) __syncthreads();
+            if (n_stages > 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's copies, before they are published
+                __syncthreads();
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {

@@ -30,13 +30,15 @@ class _timed:
         self.name, self.work, self.ref = name, work, ref
 
     def __enter__(self):
-        if TIMERS is not None:
+        # (no event pairs while a HIP graph is being recorded: they would become nodes of the graph)
+        self.on = TIMERS is not None and not torch.cuda.is_current_stream_capturing()
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record(torch.cuda.current_stream(self.ref.device))
 
     def __exit__(self, *exc):
-        if TIMERS is not None:
+        if self.on and TIMERS is not None:
             self.e1.record(torch.cuda.current_stream(self.ref.device))
             dev = self.ref.device
             TIMERS.setdefault(self.name, []).append((self.e0, self.e1, self.work,

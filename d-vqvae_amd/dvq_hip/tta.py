@@ -133,6 +133,12 @@ class GraspRefiner:
         if st["obj"] is None or st["obj"].shape != obj.shape:
             st["obj"] = torch.empty_like(obj, memory_format=torch.contiguous_format)
             st["graph"] = None
+        # a recorded graph holds the hand layer's constant tables by address and the step sizes and loss weights by
+        # value: drop it when any of them has changed since the recording
+        self.rh_mano._device_consts()
+        baked = (self.rh_mano._consts_key, self.lr, self.momentum, self.w_penetr, self.w_contact)
+        if st.get("baked") != baked:
+            st["graph"], st["baked"] = None, baked
         st["obj"].copy_(obj)
         for dst, src in zip(st["p"], (param[:, 10:13], param[:, 13:58], param[:, 58:61])):
             dst.copy_(src)

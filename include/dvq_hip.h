@@ -230,8 +230,8 @@ typedef struct {
     const int* faces;                  /* [F,3]                                                           */
     const int* vert_face_ptr;          /* [V+1] offsets into vert_face                                    */
     const int* vert_face;              /* faces incident to each vertex, grouped by vertex                */
-    const int* search_order;           /* [V] all vertex ids, the n_contact contact-set vertices first;   */
-                                       /* equal distances resolve to the vertex that comes first here     */
+    const int* search_order;           /* [V] all vertex ids: the n_contact contact-set vertices, ascending, */
+                                       /* then the others, ascending; equal distances go to the lowest id    */
 } DvqHandMesh;
 
 int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, int64_t obj_chan_stride, int64_t obj_point_stride,

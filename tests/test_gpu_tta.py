@@ -118,6 +118,32 @@ def test_contact_gradient_matches_oracle(dev, hand):
     assert torch.equal(gv3, got["grad_verts"])
 
 
+def test_exact_distance_ties_go_to_the_lowest_vertex_id(dev, hand):
+    """Two vertices at one position, one inside the contact set and one outside: the nearest-vertex index of a point
+    next to them is the LOWER id whichever part holds it (the kernel searches the contact set first; the rule is that
+    of a plain first-minimum scan over all vertices, which the oracle states too)."""
+    from dvq_hip import ops
+    from dvq_hip.tta import GraspRefiner
+    from oracle import tta_oracle as T
+    rh, sd = hand
+    param, obj, obj_pc = _scene(sd, 1, seed=5)
+    r = GraspRefiner(rh)
+    verts = r.loss_and_grad(obj_pc.to(dev), param.to(dev))["verts"].clone()
+    contact = sorted(CONTACT_VERTS)
+    rest = sorted(set(range(778)) - set(contact))
+    c_hi, n_lo = contact[-1], rest[0]             # contact id above a non-contact id
+    c_lo, n_hi = contact[0], rest[-1]             # contact id below a non-contact id
+    assert n_lo < c_hi and c_lo < n_hi
+    verts[0, c_hi] = verts[0, n_lo]
+    verts[0, n_hi] = verts[0, c_lo]
+    pts = obj.clone().to(dev)
+    pts[0, 0] = verts[0, n_lo] + 1e-4
+    pts[0, 1] = verts[0, c_lo] - 1e-4
+    nn = torch.zeros(1, pts.shape[1], dtype=torch.int32, device=dev)
+    ops.tta_contact_grad(pts.contiguous(), verts, r.mesh, T.CONTACT_DIST_SQ, 120.0, 7500.0, 5.0, 1.0, nn_idx=nn, points_last=False)
+    assert int(nn[0, 0]) == n_lo and int(nn[0, 1]) == c_lo
+
+
 def test_no_contact_and_repeatability(dev, hand):
     from dvq_hip.tta import GraspRefiner
     rh, sd = hand
