@@ -114,6 +114,140 @@ __device__ __forceinline__ void pg_add_block(const char* base, int lane, float* 
     }
 }
 
+// Epilogue of one sample tile: acc[t] = tile of output-feature block ob[t] (for GATE: t < NO/2 the tanh half, the rest
+// the matching sigmoid half).  Register i of a tile <-> feature 32*ob + (i&3) + 8*(i>>2) + 4h, lane c <-> sample 32*sb + c.
+template <int DT, int EPI, int NO, typename Acc>
+__device__ __forceinline__ void pg_epilogue(const PgJobDev& job, const Acc& acc, const int* ob, int sb, int lane, int M, int N,
+                                            int SB, int relu) {
+    constexpr int UPB = PgT<DT>::UPB;
+    const int c = lane & 31, h = lane >> 5;
+    int m = sb * 32 + c;
+    const bool mvalid = m < M;
+    if (!mvalid) m = M - 1;
+    if (EPI == PG_GATE) {
+        const float* crow = job.cond + job.label[m] * N;
+#pragma unroll
+        for (int t = 0; t < NO / 2; ++t) {
+            float g[16], pre_lo[16], pre_hi[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int nlo = 32 * ob[t] + 8 * q4 + 4 * h, nhi = 32 * ob[t + NO / 2] + 8 * q4 + 4 * h;
+                const f32x4 blo = *reinterpret_cast<const f32x4*>(job.bias + nlo);
+                const f32x4 bhi = *reinterpret_cast<const f32x4*>(job.bias + nhi);
+                const f32x4 clo = *reinterpret_cast<const f32x4*>(crow + nlo);
+                const f32x4 chi = *reinterpret_cast<const f32x4*>(crow + nhi);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * q4 + q;
+                    pre_lo[i] = acc[t][0][i] + blo[q];
+                    pre_hi[i] = acc[t + NO / 2][0][i] + bhi[q];
+                    g[i] = pg_tanh(pre_lo[i] + clo[q], DT == DVQ_F32) * pg_sigmoid(pre_hi[i] + chi[q], DT == DVQ_F32);
+                }
+            }
+            pg_store_block<DT>(job.out_packed + ((int64_t)ob[t] * SB + sb) * UPB * 1024, lane, g);
+            if (job.out_pre) {
+                pg_store_block<DT>(job.out_pre + ((int64_t)ob[t] * SB + sb) * UPB * 1024, lane, pre_lo);
+                pg_store_block<DT>(job.out_pre + ((int64_t)ob[t + NO / 2] * SB + sb) * UPB * 1024, lane, pre_hi);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NO; ++t) {
+            float y[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int n0 = 32 * ob[t] + 8 * q4 + 4 * h;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(job.bias + n0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[4 * q4 + q] = acc[t][0][4 * q4 + q] + b[q];
+                if (EPI == PG_ROWS) {
+                    if (mvalid) {
+                        f32x4 o; o[0] = y[4 * q4]; o[1] = y[4 * q4 + 1]; o[2] = y[4 * q4 + 2]; o[3] = y[4 * q4 + 3];
+                        *reinterpret_cast<f32x4*>(job.out_rows + (int64_t)m * N + n0) = o;
+                    }
+                }
+            }
+            if (EPI == PG_PACK) {
+                const int64_t off = ((int64_t)ob[t] * SB + sb) * UPB * 1024;
+                if (job.resid) pg_add_block<DT>(job.resid + off, lane, y);
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) y[j] = y[j] > 0.f ? y[j] : 0.f;
+                }
+                pg_store_block<DT>(job.out_packed + off, lane, y);
+            }
+        }
+    }
+}
+
+// Up to 32 rows (one sample tile; the reference samples one grid at a time): the product is a stream of weights
+// with next to no arithmetic, so it is cut along k instead of along the samples.  A workgroup of eight waves owns
+// one output-feature block (GATE: a block and its partner in the upper half); wave w takes the 1-KiB units
+// u = w, w+8, ... of every tap -- weights and activations of a tap are both contiguous in u -- straight from
+// global memory into MFMA operands, the eight partial tiles meet in LDS and are summed in wave order (the same
+// order every time), and the first wave runs the epilogue.  N/32 (N/64) workgroups per job stream the weights
+// instead of the handful that whole 128-feature tiles would give.
+constexpr int kPgSmallWaves = 8;
+template <int DT, int EPI>
+__global__ __launch_bounds__(kPgSmallWaves * 64) void prior_gemm_small_kernel(PgJobs jobs, int M, int N, int relu) {
+    constexpr int UPB = PgT<DT>::UPB;
+    constexpr int NO = EPI == PG_GATE ? 2 : 1;
+    __shared__ float part[kPgSmallWaves][NO][16][64];
+    const PgJobDev& job = jobs.j[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_ob = N / 32;
+    int ob[NO];
+    ob[0] = blockIdx.x;
+    if (NO == 2) ob[1] = n_ob / 2 + blockIdx.x;
+    f32x16 acc[NO][1];
+#pragma unroll
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][0][i] = 0.f;
+    for (int tp = 0; tp < job.n_taps; ++tp) {
+        const int units = job.taps[tp].kb * UPB;
+        const char* x = job.taps[tp].x + lane * 16;
+        const char* w0 = job.taps[tp].w + (int64_t)ob[0] * units * 1024 + lane * 16;
+        const char* w1 = job.taps[tp].w + (int64_t)ob[NO - 1] * units * 1024 + lane * 16;
+#pragma unroll 4
+        for (int u = wave; u < units; u += kPgSmallWaves) {
+            if constexpr (DT == DVQ_BF16) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(x + (int64_t)u * 1024);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(w0 + (int64_t)u * 1024), xf, acc[0][0], 0, 0, 0);
+                if (NO == 2)
+                    acc[NO - 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(w1 + (int64_t)u * 1024), xf, acc[NO - 1][0], 0, 0, 0);
+            } else {
+                const f32x4 xf = *reinterpret_cast<const f32x4*>(x + (int64_t)u * 1024);
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w0 + (int64_t)u * 1024);
+                f32x4 wb = wa;
+                if (NO == 2) wb = *reinterpret_cast<const f32x4*>(w1 + (int64_t)u * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xf[j], acc[0][0], 0, 0, 0);
+                    if (NO == 2) acc[NO - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], xf[j], acc[NO - 1][0], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[wave][t][i][lane] = acc[t][0][i];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = part[0][t][i][lane];
+#pragma unroll
+            for (int w = 1; w < kPgSmallWaves; ++w) v += part[w][t][i][lane];
+            acc[t][0][i] = v;
+        }
+    pg_epilogue<DT, EPI, NO>(job, acc, ob, 0, lane, M, N, 1, relu);
+}
+
 // grid: x = output-feature group (NO tiles of 32; for GATE NO/2 + the matching NO/2 of the upper
 //       half), y = group of 4 sample tiles (one per wave), z = job.  One workgroup per CU.
 //
@@ -240,69 +374,7 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
         }
     }
 
-    // ---- epilogue.  register i of a tile <-> feature 32*ob + (i&3) + 8*(i>>2) + 4h, lane c <-> sample 32*sb + c
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const bool live = s == 0 ? live0 : live1;
-        if (!live) continue;
-        int m = sb[s] * 32 + c;
-        const bool mvalid = m < M;
-        if (!mvalid) m = M - 1;
-        if (EPI == PG_GATE) {
-            const float* crow = job.cond + job.label[m] * N;
-#pragma unroll
-            for (int t = 0; t < NO / 2; ++t) {
-                float g[16], pre_lo[16], pre_hi[16];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int nlo = 32 * ob[t] + 8 * q4 + 4 * h, nhi = 32 * ob[t + NO / 2] + 8 * q4 + 4 * h;
-                    const f32x4 blo = *reinterpret_cast<const f32x4*>(job.bias + nlo);
-                    const f32x4 bhi = *reinterpret_cast<const f32x4*>(job.bias + nhi);
-                    const f32x4 clo = *reinterpret_cast<const f32x4*>(crow + nlo);
-                    const f32x4 chi = *reinterpret_cast<const f32x4*>(crow + nhi);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = 4 * q4 + q;
-                        pre_lo[i] = acc[t][s][i] + blo[q];
-                        pre_hi[i] = acc[t + NO / 2][s][i] + bhi[q];
-                        g[i] = pg_tanh(pre_lo[i] + clo[q], DT == DVQ_F32) * pg_sigmoid(pre_hi[i] + chi[q], DT == DVQ_F32);
-                    }
-                }
-                pg_store_block<DT>(job.out_packed + ((int64_t)ob[t] * SB + sb[s]) * UPB * 1024, lane, g);
-                if (job.out_pre) {
-                    pg_store_block<DT>(job.out_pre + ((int64_t)ob[t] * SB + sb[s]) * UPB * 1024, lane, pre_lo);
-                    pg_store_block<DT>(job.out_pre + ((int64_t)ob[t + NO / 2] * SB + sb[s]) * UPB * 1024, lane, pre_hi);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < NO; ++t) {
-                float y[16];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int n0 = 32 * ob[t] + 8 * q4 + 4 * h;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(job.bias + n0);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) y[4 * q4 + q] = acc[t][s][4 * q4 + q] + b[q];
-                    if (EPI == PG_ROWS) {
-                        if (mvalid) {
-                            f32x4 o; o[0] = y[4 * q4]; o[1] = y[4 * q4 + 1]; o[2] = y[4 * q4 + 2]; o[3] = y[4 * q4 + 3];
-                            *reinterpret_cast<f32x4*>(job.out_rows + (int64_t)m * N + n0) = o;
-                        }
-                    }
-                }
-                if (EPI == PG_PACK) {
-                    const int64_t off = ((int64_t)ob[t] * SB + sb[s]) * UPB * 1024;
-                    if (job.resid) pg_add_block<DT>(job.resid + off, lane, y);
-                    if (relu) {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) y[j] = y[j] > 0.f ? y[j] : 0.f;
-                    }
-                    pg_store_block<DT>(job.out_packed + off, lane, y);
-                }
-            }
-        }
-    }
+    if (live0) pg_epilogue<DT, EPI, NO>(job, acc, ob, sb[0], lane, M, N, SB, relu);
 }
 
 // W [N, K] (fp32, element (n,k) at W[n*ldn + k*ldk]) -> packed A-fragment units
@@ -709,6 +781,21 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
         if (epilogue == PG_ROWS && !s.out_rows) return fail(DVQ_EINVAL, "prior_gemm: out_rows missing");
     }
     const int SB = (M + 31) / 32;
+    hipStream_t st = as_stream(stream);
+    if (SB == 1) {   // one sample tile: k-split kernel
+        const dim3 grid(epilogue == PG_GATE ? N / 64 : N / 32, 1, n_jobs), blk(kPgSmallWaves * 64);
+#define DVQ_PG_SMALL(E)                                                                                                     \
+    do {                                                                                                                    \
+        if (dtype == DVQ_F32) hipLaunchKernelGGL((prior_gemm_small_kernel<DVQ_F32, E>), grid, blk, 0, st, dev, M, N, relu); \
+        else hipLaunchKernelGGL((prior_gemm_small_kernel<DVQ_BF16, E>), grid, blk, 0, st, dev, M, N, relu);                 \
+    } while (0)
+        if (epilogue == PG_PACK) DVQ_PG_SMALL(PG_PACK);
+        else if (epilogue == PG_GATE) DVQ_PG_SMALL(PG_GATE);
+        else if (epilogue == PG_ROWS) DVQ_PG_SMALL(PG_ROWS);
+        else return fail(DVQ_EINVAL, "prior_gemm: unknown epilogue %d", epilogue);
+#undef DVQ_PG_SMALL
+        return check_launch("prior_gemm(small)");
+    }
     const int upb = dtype == DVQ_F32 ? 4 : 2;
     // k-blocks of 32 features per LDS stage (an fp32 stage of one block is as large as a bf16 stage of two)
     const int ks = (dtype == DVQ_F32 || M >= 4096) ? 1 : 2;
@@ -723,7 +810,6 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
     const int no = ((int64_t)(N / 128) * gy * n_jobs >= want || (N % 64) != 0 || (epilogue == PG_GATE && (N % 128) != 0)) ? 4 : 2;
     const dim3 grid(N / (32 * no), gy, n_jobs);
     const size_t lds = (size_t)kPgRing * (no * ks * upb + kPgWaves * ks * upb) * 1024;
-    hipStream_t st = as_stream(stream);
     const dim3 blk(kPgWaves * 64);
 #define DVQ_PG_LAUNCH3(D, E, NO_, KS_)                                                                   \
     do {                                                                                                 \
