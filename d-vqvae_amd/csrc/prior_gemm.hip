@@ -449,6 +449,39 @@ __global__ void prior_embed_kernel(const int64_t* __restrict__ idx, int64_t idx_
     out[t] = pg_pack_row_piece<DT>(table + row * d, fb, s, h);
 }
 
+// out_b(packed)[m] <- table_b(packed)[idx[m]] for a list of buffers in one launch: rows of packed activations that
+// were computed once per class, handed out to the rows of a batch by their class (grid.y = buffer).
+constexpr int kPgGatherMax = 96;
+struct PgGatherOne {
+    const uint4* table;
+    uint4* out;
+    int features;
+};
+struct PgGatherList {
+    PgGatherOne e[kPgGatherMax];
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void prior_gather_rows_kernel(PgGatherList list, const int64_t* __restrict__ idx, int M, int V) {
+    constexpr int UPB = PgT<DT>::UPB;
+    const PgGatherOne& g = list.e[blockIdx.y];
+    const int SB = (M + 31) / 32, SBV = (V + 31) / 32;
+    const int64_t total = (int64_t)(g.features / 32) * SB * UPB * 64;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(t & 63);
+        const int64_t unit = t >> 6;
+        const int s = (int)(unit % UPB);
+        const int sbk = (int)((unit / UPB) % SB);
+        const int fb = (int)((unit / UPB) / SB);
+        const int c = l & 31, h = l >> 5;
+        int m = sbk * 32 + c;
+        if (m >= M) m = M - 1;                      // the unused rows of the last block repeat the last row
+        int64_t row = idx[m];
+        if (row < 0) row = 0;
+        if (row >= V) row = V - 1;
+        g.out[t] = g.table[(((int64_t)fb * SBV + (row >> 5)) * UPB + s) * 64 + h * 32 + (row & 31)];
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Vertical stack of one grid row in one launch (kernel-3 layers): the three cells of the row read the same input
@@ -710,6 +743,29 @@ extern "C" int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const flo
     else
         hipLaunchKernelGGL(prior_embed_kernel<DVQ_BF16>, grid, dim3(256), 0, as_stream(stream), idx, idx_stride, table, V, M, d, reinterpret_cast<uint4*>(out));
     return check_launch("prior_embed");
+}
+
+extern "C" int dvq_prior_gather_rows(const DvqPriorGather* list, int n, const int64_t* idx, int M, int V, int dtype, void* stream) {
+    if (!list || n < 1 || n > kPgGatherMax || !idx || M < 1 || V < 1)
+        return fail(DVQ_EINVAL, "prior_gather_rows: 1..%d buffers, an index per row, M and V >= 1", kPgGatherMax);
+    if (!pg_dtype_ok(dtype)) return fail(DVQ_EINVAL, "prior_gather_rows: dtype must be DVQ_F32 or DVQ_BF16");
+    PgGatherList dev;
+    int max_features = 0;
+    for (int b = 0; b < n; ++b) {
+        if (!list[b].table || !list[b].out || list[b].features < 32 || (list[b].features % 32))
+            return fail(DVQ_EINVAL, "prior_gather_rows: buffer %d: table, out and a multiple of 32 features are required", b);
+        dev.e[b].table = reinterpret_cast<const uint4*>(list[b].table);
+        dev.e[b].out = reinterpret_cast<uint4*>(list[b].out);
+        dev.e[b].features = list[b].features;
+        if (list[b].features > max_features) max_features = list[b].features;
+    }
+    const int64_t total = (int64_t)(max_features / 32) * ((M + 31) / 32) * (dtype == DVQ_F32 ? 4 : 2) * 64;
+    int64_t gx = (total + 255) / 256;
+    if (gx > 4096) gx = 4096;                       // grid-stride beyond that
+    const dim3 grid((unsigned)gx, (unsigned)n);
+    if (dtype == DVQ_F32) hipLaunchKernelGGL(prior_gather_rows_kernel<DVQ_F32>, grid, dim3(256), 0, as_stream(stream), dev, idx, M, V);
+    else hipLaunchKernelGGL(prior_gather_rows_kernel<DVQ_BF16>, grid, dim3(256), 0, as_stream(stream), dev, idx, M, V);
+    return check_launch("prior_gather_rows");
 }
 
 extern "C" int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream) {

@@ -55,6 +55,10 @@ class DvqPriorVRow(ctypes.Structure):
                 ("out_pre", c_void_p * 3)]
 
 
+class DvqPriorGather(ctypes.Structure):
+    _fields_ = [("table", c_void_p), ("out", c_void_p), ("features", c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/dvq_hip.h one to one
 SIGNATURES = {
     "dvq_version": (c_int, []),
@@ -82,6 +86,7 @@ SIGNATURES = {
     "dvq_prior_pack_weight": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_gemm": (c_int, [POINTER(DvqPriorJob), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dvq_prior_gather_rows": (c_int, [POINTER(DvqPriorGather), c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dvq_prior_vrow": (c_int, [POINTER(DvqPriorVRow), c_int, c_int, c_void_p]),
     "dvq_prior_sample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import DVQ_BF16, DVQ_F32, DvqHandMesh, DvqManoConsts, DvqPointMlp, DvqPriorJob, DvqPriorVRow
+from ._lib import DVQ_BF16, DVQ_F32, DvqHandMesh, DvqManoConsts, DvqPointMlp, DvqPriorGather, DvqPriorJob, DvqPriorVRow
 
 
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
@@ -466,6 +466,24 @@ def prior_sample(logits: torch.Tensor, u: torch.Tensor, x_out: torch.Tensor, tab
         rc = _lib.load().dvq_prior_sample(_p(logits), n, M, _p(u), u.stride(0), _p(x_out), x_out.stride(0), _p(table),
                                           0 if table is None else table.shape[1], dtype_code, _p(emb_out), _stream(logits))
     _lib.check(rc, "dvq_prior_sample")
+
+
+def prior_gather_rows(pairs, idx: torch.Tensor, M: int, V: int, dtype_code: int = DVQ_BF16) -> None:
+    """out[m] <- table[idx[m]] for every (table, out, features) of `pairs`: packed activations of V rows handed out to
+    the M rows of a batch.  One launch per 96 buffers."""
+    _need_gpu(idx)
+    if idx.dtype != torch.int64 or idx.dim() != 1 or idx.shape[0] != M or not idx.is_contiguous():
+        raise RuntimeError("prior_gather_rows: idx must be a contiguous int64 vector with one entry per row")
+    lib = _lib.load()
+    for b in range(0, len(pairs), 96):
+        part = pairs[b:b + 96]
+        arr = (DvqPriorGather * len(part))()
+        for k, (table, out, features) in enumerate(part):
+            _need_gpu(table, out)
+            arr[k].table, arr[k].out, arr[k].features = table.data_ptr(), out.data_ptr(), features
+        with torch.cuda.device(idx.device), _timed("prior_gather_rows", (M, V, len(part)), idx):
+            rc = lib.dvq_prior_gather_rows(arr, len(part), _p(idx), M, V, dtype_code, _stream(idx))
+        _lib.check(rc, "dvq_prior_gather_rows")
 
 
 def prior_vrow(rows, k_blocks: int, bias, cond, label, out_packed, out_pre, M: int, N: int) -> None:

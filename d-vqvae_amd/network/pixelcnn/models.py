@@ -119,10 +119,13 @@ class GatedPixelCNN(nn.Module):
         self._packed_key = None
         self._packed = None
         self._bufs = {}
+        self._cls = None                       # per-class constants of the weights (see _class_rows)
         self.use_graph = True                  # replay generate() as a captured HIP graph
         self.split = 1                         # sub-batches evaluated side by side (own streams and graphs)
         self.split_min_rows = 2048             # ... for batches of at least this many rows
         self.vrow_min_rows = 3072              # fused vertical-row kernel (bf16) from this many rows per (sub-)batch
+        self.class_rows = True                 # grid row 0's vertical stack and cell (0,0) once per class, not per row
+        self.class_rows_min_rows = 1           # ... for batches of at least this many rows
 
     def forward(self, x, label):
         shp = x.size() + (-1,)
@@ -154,6 +157,7 @@ class GatedPixelCNN(nn.Module):
             self._packed = ([_PackedTaps(layer, code) for layer in self.layers], head)
             self._packed_key = key
             self._bufs = {}
+            self._cls = None
         return self._packed
 
     def graph_ready(self, batch_size, shape=(3, 3)):
@@ -164,28 +168,31 @@ class GatedPixelCNN(nn.Module):
             return True
         b = self._bufs.get((batch_size, shape[0], shape[1], str(self.embedding.weight.device)))
         return (self._weights_key() == self._packed_key and b is not None and b.get("graph") is not None
-                and b.get("split") == (self._n_parts(batch_size), self.vrow_min_rows))
+                and b.get("split") == self._plan(batch_size))
 
     def _act_buffers(self, B, H, W, dev, part=None):
         """Packed activation buffers for a batch of B grids, allocated once per (B, H, W); `part` tells the
         buffer sets of the sub-batches of one split batch apart.  A new batch size drops the old buffers."""
         key = (B, H, W, str(dev)) if part is None else (B, H, W, str(dev), part)
         if key not in self._bufs:
-            L, d = len(self.layers), self.dim
-            code = self._code()
-            e = lambda f, zero=False: ops.prior_packed_empty(B, f, dev, zero, code)
             if part is None:
                 self._bufs = {}
-            self._bufs[key] = dict(
-                XV=[[[e(d) for _ in range(W)] for _ in range(H)] for _ in range(L + 1)],
-                HV=[[e(2 * d) for _ in range(W)] for _ in range(L)],
-                XH=[[e(d) for _ in range(L + 1)] for _ in range(2)],
-                OUT=e(d), HID=e(self.output_conv[0].out_channels), Z=e(d, True),
-                logits=torch.empty(B, self.output_conv[2].out_channels, dtype=torch.float32, device=dev),
-                emb=self.embedding.weight.detach().float().contiguous(),
-                label=torch.zeros(B, dtype=torch.int64, device=dev),
-                u=torch.zeros(B, H * W, dtype=torch.float64, device=dev), graph=None, x=None)
+            self._bufs[key] = self._new_buffers(B, H, W, dev)
         return self._bufs[key]
+
+    def _new_buffers(self, B, H, W, dev):
+        L, d = len(self.layers), self.dim
+        code = self._code()
+        e = lambda f, zero=False: ops.prior_packed_empty(B, f, dev, zero, code)
+        return dict(
+            XV=[[[e(d) for _ in range(W)] for _ in range(H)] for _ in range(L + 1)],
+            HV=[[e(2 * d) for _ in range(W)] for _ in range(L)],
+            XH=[[e(d) for _ in range(L + 1)] for _ in range(2)],
+            OUT=e(d), HID=e(self.output_conv[0].out_channels), Z=e(d, True),
+            logits=torch.empty(B, self.output_conv[2].out_channels, dtype=torch.float32, device=dev),
+            emb=self.embedding.weight.detach().float().contiguous(),
+            label=torch.zeros(B, dtype=torch.int64, device=dev),
+            u=torch.zeros(B, H * W, dtype=torch.float64, device=dev), graph=None, x=None)
 
     @torch.no_grad()
     def generate(self, x_start, label, shape=(3, 3), batch_size=64, generator=None, return_probs=False,
@@ -208,10 +215,12 @@ class GatedPixelCNN(nn.Module):
         self._prepared_hip()
         bufs = self._act_buffers(B, H, W, dev)
         bufs["label"].copy_(label.reshape(-1).to(torch.int64))
+        if self._by_class(B):
+            self._class_rows(shape, B >= self.vrow_min_rows)        # before any graph is recorded
         if uniforms is None or return_probs or not self.use_graph:
             return self._run_hip(bufs, shape, B, generator, return_probs, uniforms)
         bufs["u"].copy_(uniforms)
-        if bufs.get("graph") is None or bufs.get("split") != (self._n_parts(B), self.vrow_min_rows):
+        if bufs.get("graph") is None or bufs.get("split") != self._plan(B):
             n_parts = self._n_parts(B)
             parts = None
             if n_parts > 1:
@@ -241,7 +250,7 @@ class GatedPixelCNN(nn.Module):
                         pb["label"].copy_(bufs["label"][a:b])
                         self._run_hip(pb, shape, b - a, None, False, bufs["u"][a:b], x_out=bufs["x"][a:b])
                     graphs.append(g)
-            bufs["graph"], bufs["split"], bufs["parts"] = graphs, (n_parts, self.vrow_min_rows), parts
+            bufs["graph"], bufs["split"], bufs["parts"] = graphs, self._plan(B), parts
         if bufs["parts"] is None:
             bufs["graph"][0].replay()
         else:
@@ -254,65 +263,127 @@ class GatedPixelCNN(nn.Module):
                 main.wait_stream(st)
         return bufs["x"].clone()
 
+    def _plan(self, B):
+        """What a recorded graph of batch size B depends on besides the weights."""
+        return (self._n_parts(B), self.vrow_min_rows, self.class_rows, self.class_rows_min_rows)
+
     def _n_parts(self, B):
         return self.split if (self.split > 1 and B >= self.split_min_rows) else 1
 
-    def _run_hip(self, bufs, shape, B, generator, return_probs, uniforms, x_out=None):
-        """Per grid row one launch per layer for the vertical stack (3 cells at once, gate fused), per
-        cell two launches per layer for the horizontal stack (taps + projected vertical features +
-        gate; residual 1x1), two for the head, then the sample and its embedding."""
+    def _gemm(self, jobs, M, N, epi, relu=False):
+        ops.prior_gemm(jobs, M, N, epi, relu, self.embedding.weight, self._packed_key[1])
+
+    def _vertical_row(self, bufs, i, M, shape, label, use_vrow):
+        """Vertical stack of grid row i for all its cells: XV[l+1][i][:] and the pre-gate features HV[l][:]."""
         H, W = shape
-        layers, (wo1, bo1, wo2, bo2) = self._packed
+        layers = self._packed[0]
         code = self._packed_key[1]
-        dev = self.embedding.weight.device
-        XV, HV, XHb, OUT, HID, Z, logits = (bufs[k] for k in ("XV", "HV", "XH", "OUT", "HID", "Z", "logits"))
+        XV, HV, Z = bufs["XV"], bufs["HV"], bufs["Z"]
+        d = self.dim
+        kb = d // 32
+        for l, t in enumerate(layers):
+            if code == DVQ_BF16 and W == 3 and t.kernel == 3 and not t.mask_a and use_vrow:
+                # all three cells of the row in one launch: every input column and every tap is fetched once
+                # (smaller batches are latency-bound: per-cell launches)
+                rows = [([XV[l][i + da][c] for c in range(3)], [t.vert[(da, db)] for db in (-1, 0, 1)])
+                        for da in (-1, 0) if i + da >= 0]
+                ops.prior_vrow(rows, kb, t.vert_bias, t.cond, label, [XV[l + 1][i][j] for j in range(3)],
+                               [HV[l][j] for j in range(3)], M, 2 * d)
+                continue
+            jobs = []
+            for j in range(W):
+                taps = [(XV[l][i + da][j + db], w, kb) for (da, db), w in t.vert.items()
+                        if 0 <= i + da < H and 0 <= j + db < W and (l > 0 or i + da < i)]
+                if not taps:                                     # nothing above this row: bias only
+                    taps = [(Z, next(iter(t.vert.values())), kb)]
+                jobs.append(ops.prior_job(taps, t.vert_bias, cond=t.cond, label=label, out_packed=XV[l + 1][i][j],
+                                          out_pre=HV[l][j]))
+            self._gemm(jobs, M, 2 * d, ops.PRIOR_GATE)
+
+    def _horizontal_cell(self, bufs, i, j, M, label):
+        """Horizontal stack and output head of cell (i, j): two launches per layer (taps + projected vertical
+        features + gate; residual 1x1), two for the head; leaves the cell's logits in bufs["logits"]."""
+        layers, (wo1, bo1, wo2, bo2) = self._packed
+        XV, HV, XHb, OUT, HID, logits = (bufs[k] for k in ("XV", "HV", "XH", "OUT", "HID", "logits"))
         L, d = len(layers), self.dim
         kb = d // 32
+        XH, XHp = XHb[j & 1], XHb[(j & 1) ^ 1]
+        for l, t in enumerate(layers):
+            taps = []
+            for db, w in t.horiz.items():
+                c = j + db
+                if c < 0:
+                    continue
+                if l == 0:
+                    taps.append((XV[0][i][c], w, kb))
+                elif c == j:
+                    taps.append((XH[l], w, kb))
+                elif c == j - 1:
+                    taps.append((XHp[l], w, kb))
+            taps.append((HV[l][j], t.v2h, 2 * kb))
+            self._gemm([ops.prior_job(taps, t.horiz_bias, cond=t.cond, label=label, out_packed=OUT)], M, 2 * d, ops.PRIOR_GATE)
+            self._gemm([ops.prior_job([(OUT, t.resid, kb)], t.resid_bias, resid=XH[l] if t.residual else None,
+                                      out_packed=XH[l + 1])], M, d, ops.PRIOR_PACK)
+        self._gemm([ops.prior_job([(XH[L], wo1, kb)], bo1, out_packed=HID)], M, bo1.numel(), ops.PRIOR_PACK, True)
+        self._gemm([ops.prior_job([(HID, wo2, bo1.numel() // 32)], bo2, out_rows=logits)], M, logits.shape[1], ops.PRIOR_ROWS)
+
+    # What the loop computes before anything has been drawn depends on a row's class alone: the vertical stack of
+    # grid row 0 (nothing above it) and the whole of cell (0, 0) (nothing left of it), logits included.  Like the
+    # packed weights they are constants of the checkpoint: evaluated for ONE row per class with the same kernels when
+    # the weights are first used (_class_rows) and handed out to the rows of a batch by their label
+    # (_first_row_by_class) -- bit-equal to evaluating every row.
+    def _by_class(self, B):
+        return self.class_rows and B >= self.class_rows_min_rows
+
+    def _class_rows(self, shape, use_vrow):
+        """Buffers of the per-class evaluation for this grid shape (and vertical-stack kernel), computed on first
+        use after the weights changed."""
+        dev = self.embedding.weight.device
+        key = (shape, use_vrow, str(dev))
+        if self._cls is None:
+            self._cls = {}
+        if key not in self._cls:
+            V = self._packed[0][0].cond.shape[0]
+            cls = self._new_buffers(V, shape[0], shape[1], dev)
+            cls["label"].copy_(torch.arange(V, dtype=torch.int64, device=dev))
+            self._vertical_row(cls, 0, V, shape, cls["label"], use_vrow)
+            self._horizontal_cell(cls, 0, 0, V, cls["label"])
+            self._cls[key] = cls
+        return self._cls[key]
+
+    def _first_row_by_class(self, bufs, B, shape, label, use_vrow):
+        H, W = shape
+        layers = self._packed[0]
+        L, d = len(layers), self.dim
+        cls = self._class_rows(shape, use_vrow)
+        V = cls["label"].shape[0]
+        pairs = [(cls["XV"][l][0][j], bufs["XV"][l][0][j], d) for l in range(1, L) for j in range(W)]       # read by row 1
+        pairs += [(cls["HV"][l][j], bufs["HV"][l][j], 2 * d) for l in range(L) for j in range(1, W)]         # cells (0, 1..)
+        pairs += [(cls["XH"][0][l], bufs["XH"][0][l], d) for l in range(1, L)]                              # cell (0, 1)
+        ops.prior_gather_rows(pairs, label, B, V, self._packed_key[1])
+        ops.vq_gather(label, cls["logits"], out=bufs["logits"])
+
+    def _run_hip(self, bufs, shape, B, generator, return_probs, uniforms, x_out=None):
+        """Grid row by grid row: the vertical stack of the row, then per cell the horizontal stack, the head and
+        the draw (with the embedding of the drawn code as the next cell's input)."""
+        H, W = shape
+        code = self._packed_key[1]
+        dev = self.embedding.weight.device
+        XV, logits = bufs["XV"], bufs["logits"]
         emb = bufs["emb"]
         label = bufs["label"]
         x = torch.zeros((B, H, W), dtype=torch.int64, device=dev) if x_out is None else x_out
-        n_out = logits.shape[1]
         probs_all = []
-        gemm = lambda jobs, N, epi, relu=False: ops.prior_gemm(jobs, B, N, epi, relu, emb, code)
+        use_vrow = B >= self.vrow_min_rows
+        by_class = self._by_class(B)
         for i in range(H):
-            for l, t in enumerate(layers):
-                if code == DVQ_BF16 and W == 3 and t.kernel == 3 and not t.mask_a and B >= self.vrow_min_rows:
-                    # (smaller batches are latency-bound: per-cell launches)
-                    # all three cells of the row in one launch: every input column and every tap is fetched once
-                    rows = [([XV[l][i + da][c] for c in range(3)], [t.vert[(da, db)] for db in (-1, 0, 1)])
-                            for da in (-1, 0) if i + da >= 0]
-                    ops.prior_vrow(rows, kb, t.vert_bias, t.cond, label, [XV[l + 1][i][j] for j in range(3)],
-                                   [HV[l][j] for j in range(3)], B, 2 * d)
-                    continue
-                jobs = []
-                for j in range(W):
-                    taps = [(XV[l][i + da][j + db], w, kb) for (da, db), w in t.vert.items()
-                            if 0 <= i + da < H and 0 <= j + db < W and (l > 0 or i + da < i)]
-                    if not taps:                                     # nothing above this row: bias only
-                        taps = [(Z, next(iter(t.vert.values())), kb)]
-                    jobs.append(ops.prior_job(taps, t.vert_bias, cond=t.cond, label=label, out_packed=XV[l + 1][i][j],
-                                              out_pre=HV[l][j]))
-                gemm(jobs, 2 * d, ops.PRIOR_GATE)
+            if i == 0 and by_class:
+                self._first_row_by_class(bufs, B, shape, label, use_vrow)
+            else:
+                self._vertical_row(bufs, i, B, shape, label, use_vrow)
             for j in range(W):
-                XH, XHp = XHb[j & 1], XHb[(j & 1) ^ 1]
-                for l, t in enumerate(layers):
-                    taps = []
-                    for db, w in t.horiz.items():
-                        c = j + db
-                        if c < 0:
-                            continue
-                        if l == 0:
-                            taps.append((XV[0][i][c], w, kb))
-                        elif c == j:
-                            taps.append((XH[l], w, kb))
-                        elif c == j - 1:
-                            taps.append((XHp[l], w, kb))
-                    taps.append((HV[l][j], t.v2h, 2 * kb))
-                    gemm([ops.prior_job(taps, t.horiz_bias, cond=t.cond, label=label, out_packed=OUT)], 2 * d, ops.PRIOR_GATE)
-                    gemm([ops.prior_job([(OUT, t.resid, kb)], t.resid_bias, resid=XH[l] if t.residual else None,
-                                        out_packed=XH[l + 1])], d, ops.PRIOR_PACK)
-                gemm([ops.prior_job([(XH[L], wo1, kb)], bo1, out_packed=HID)], bo1.numel(), ops.PRIOR_PACK, True)
-                gemm([ops.prior_job([(HID, wo2, bo1.numel() // 32)], bo2, out_rows=logits)], n_out, ops.PRIOR_ROWS)
+                if not (i == 0 and j == 0 and by_class):
+                    self._horizontal_cell(bufs, i, j, B, label)
                 if uniforms is not None and not return_probs:
                     # softmax, draw, grid write and embedding of the drawn code in one launch
                     ops.prior_sample(logits, uniforms[:, i * W + j], x[:, i, j], emb, XV[0][i][j], code)

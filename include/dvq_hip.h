@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 108   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 109   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -286,6 +286,16 @@ int dvq_prior_pack_weight(const float* W, int64_t ldn, int64_t ldk, int N, int K
 int dvq_prior_embed(const int64_t* idx, int64_t idx_stride, const float* table, int V, int M, int d, int dtype, void* out,
                     void* stream);
 int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N, int epilogue, int relu, int dtype, void* stream);
+/* out_b[m] = table_b[idx[m]] for b = 0..n-1 (n <= 96), tables and outputs packed activations of `dtype`: tables hold V
+ * rows, outputs M rows, `features` each.  For what the sampling loop computes from the class label alone
+ * (models.py:176-198 with nothing sampled yet: the vertical stack above the first grid row and the whole first cell),
+ * evaluated once per class and handed out to the rows of the batch.  idx is clamped to [0, V). */
+typedef struct {
+    const void* table;
+    void* out;
+    int features;
+} DvqPriorGather;
+int dvq_prior_gather_rows(const DvqPriorGather* list, int n, const int64_t* idx, int M, int V, int dtype, void* stream);
 /* Vertical stack of one grid row of a kernel-3 layer (models.py:72-73 for the three cells of a row at once):
  *   y_j = bias + sum over input rows r and columns c with |c - j| <= 1 of  w[r][c - j + 1] * x[r][c],   j = 0, 1, 2
  * followed by the GATE epilogue of dvq_prior_gemm per cell (out_packed[j]: N/2 features; out_pre[j], optional: N).

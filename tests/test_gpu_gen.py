@@ -127,6 +127,40 @@ def test_prior_bf16_kernels_vs_fp32():
     assert torch.equal(x16c[0], x16[40])       # and of batch size, down to one
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prior_rows_by_class_equal_rows_evaluated_one_by_one(dtype):
+    """Grid row 0's vertical stack and cell (0, 0) see nothing but the class label; generate() evaluates them once per
+    class and hands the rows out (dvq_prior_gather_rows).  Same kernels, same numbers: the sampled grids and the
+    per-cell distributions must be bit-equal to evaluating every row, at a ragged batch and at one grid."""
+    from dvq_hip import ops, rng
+    model, _ = build()
+    prior = model.GatedPixelCNN
+    prior.compute_dtype = dtype
+    for B in (301, 1):
+        lab = torch.randint(0, 128, (B,), device=DEV, generator=torch.Generator(DEV).manual_seed(4))
+        u = rng.uniforms(torch.arange(B, device=DEV), 9, seed=11)
+        out = {}
+        for on in (True, False):
+            prior.class_rows = on
+            out[on] = prior.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u, return_probs=True)
+        prior.class_rows = True
+        if B > 32:                               # (one grid takes the k-split kernel: another summation order)
+            assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+        else:
+            assert (out[True][1] - out[False][1]).abs().max().item() <= (1e-5 if dtype == torch.float32 else 5e-3)
+    # the gather itself: packed rows of a table handed out by index, against prior_embed of the same rows
+    code = ops.DVQ_BF16 if dtype == torch.bfloat16 else ops.DVQ_F32
+    V, M, d = 50, 77, 96
+    g = torch.Generator(DEV).manual_seed(8)
+    table = torch.randn(V, d, device=DEV, generator=g)
+    idx = torch.randint(0, V, (M,), device=DEV, generator=g)
+    packed_table = ops.prior_embed(torch.arange(V, device=DEV), table, ops.prior_packed_empty(V, d, DEV, True, code), code)
+    want = ops.prior_embed(idx, table, ops.prior_packed_empty(M, d, DEV, True, code), code)
+    got = ops.prior_packed_empty(M, d, DEV, True, code)
+    ops.prior_gather_rows([(packed_table, got, d)], idx, M, V, code)
+    assert torch.equal(got, want)
+
+
 def test_prior_vrow_kernel_equals_three_per_cell_products():
     """The fused row kernel against three dvq_prior_gemm jobs on the same operands: same taps, another summation
     order, so the packed bf16 results may differ by an ulp of bf16 (2^-8 relative) and no more."""

@@ -134,6 +134,29 @@ def prior():
             print(f"prior.generate B={B} {str(dt)[6:]:9s}: {ms:8.3f} ms  ({1.22e9 * B / ms / 1e9:7.1f} TFLOP/s useful)", flush=True)
 
 
+def prior_classes():
+    """prior.generate with grid row 0 / cell (0,0) evaluated once per class against once per row."""
+    from network.gen_net import GenNet
+    from dvq_hip import rng
+    model = GenNet()
+    model.load_state_dict(synth.gennet_state_dict(0))
+    pr = model.GatedPixelCNN.to(dev).eval()
+    sizes = [int(v) for v in os.environ.get("DVQ_SIZES", "4096,2048,1024,512,256").split(",")]
+    for dt in (torch.bfloat16, torch.float32):
+        pr.compute_dtype = dt
+        pr.class_rows_min_rows = 1
+        for B in sizes:
+            lab = torch.randint(0, 128, (B,), device=dev)
+            u = rng.uniforms(torch.arange(B, device=dev), 9, 0)
+            res = {}
+            for on in (False, True, False, True):
+                pr.class_rows = on
+                ms = timeit(lambda: pr.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u), iters=5, warm=2)
+                res[on] = pr.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u)
+                print(f"prior.generate B={B} {str(dt)[6:]:9s} per class={int(on)}: {ms:8.3f} ms", flush=True)
+            print(f"   grids equal: {(res[True] == res[False]).float().mean().item():.6f}", flush=True)
+
+
 def prior_split():
     """prior.generate at 4096 rows with the batch cut into sub-batches on concurrent streams inside the graph."""
     from network.gen_net import GenNet
@@ -187,14 +210,19 @@ def gen():
 
 
 def gen4096():
+    """The bench step (4096 objects, bf16) with the prior's input-free part once per class / once per row."""
     from dvq_hip.pipeline import GraspGenerator
     g = GraspGenerator.synthetic(dev, seed=0, dtype=torch.bfloat16)
     obj = synth.object_clouds_device(4096, 3000, 11, dev)
     pr = g.model.GatedPixelCNN
-    for split, vmin in ((1, 3072), (2, 1024), (1, 3072), (2, 1024)):
-        pr.split, pr.vrow_min_rows = split, vmin
+    ref = None
+    for on in (False, True, False, True):
+        pr.class_rows = on
         ms = timeit(lambda: g.generate(obj), iters=10, warm=3)
-        print(f"generate B=4096 bf16 split={split}: {ms:8.3f} ms  {4096 / ms * 1e3:10.0f} grasps/s", flush=True)
+        out = g.generate(obj)["vertices"]
+        ref = out if ref is None else ref
+        print(f"generate B=4096 bf16 per class={int(on)}: {ms:8.3f} ms  {4096 / ms * 1e3:10.0f} grasps/s   "
+              f"max |dv| vs first {(out - ref).abs().max().item():.3g}", flush=True)
 
 
 def tta():
