@@ -258,11 +258,12 @@ __global__ __launch_bounds__(kPgSmallWaves * 64) void prior_gemm_small_kernel(Pg
 // in flight), then one s_barrier makes every wave's part visible and frees the buffer read R-1
 // stages ago, which is immediately refilled.
 // A 128 x 128 output tile per workgroup is all a [4096 x 1024] product leaves for each of the 256
-// CUs, so every CU pulls 16 KiB through L2 per k-block of 32 features: the product is bound by
-// L2 -> LDS bandwidth (64 FLOP per byte), not by the matrix cores.  With 4096 or more rows KS = 1
-// and R = 3 (48 KiB) keep two loads in flight per wave, which is enough to saturate that path, and
-// leave room in LDS for workgroups of the point-cloud encoder that runs beside the prior on another
-// stream; smaller batches are latency-bound and take KS = 2 (half as many barriers per product).
+// CUs (64 FLOP per byte moved from L2); 64-wide tiles, two workgroups per CU, move 1.5x the bytes and
+// are still faster: no unit is saturated (matrix pipe 17 %, L2 request rate 25 % of its peak, waves
+// waiting 41 % of their time by the counters) -- the loop is bound by the latency of a stage's
+// barrier and load wait, which a second workgroup hides and a deeper ring does not (R = 4, 5: +-1 %).
+// bf16 stages hold two k-blocks (half as many barriers per product: 7.19 -> 6.92 ms per 4096 grids),
+// fp32 stages one (the same bytes).
 template <int DT, int EPI, int NO, int KS>
 __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
     // These products form a long dependent chain of short launches; when another stream's long-running kernel
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int
     constexpr int W_UNITS = 3 * NO * 2;                      // [tap][t][q]
     constexpr int X_UNITS = 3 * kPgWaves * 2;                // [col][wave][q]
     constexpr int STAGE_BYTES = (W_UNITS + X_UNITS) * 1024;
-    constexpr int R = kPgRing;
+    constexpr int R = 3;
     constexpr int GLDS_PER_STAGE = W_UNITS / kPgWaves + 6;   // per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -788,7 +789,7 @@ extern "C" int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream)
     d.n_rows = v->n_rows; d.kb = v->k_blocks; d.bias = v->bias; d.cond = v->cond; d.label = v->label;
     const int SB = (M + 31) / 32;
     const dim3 grid(N / 128, (SB + kPgWaves - 1) / kPgWaves);
-    const size_t lds = (size_t)kPgRing * (3 * 4 * 2 + 3 * kPgWaves * 2) * 1024;
+    const size_t lds = (size_t)3 * (3 * 4 * 2 + 3 * kPgWaves * 2) * 1024;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_vrow_kernel), lds, "prior_vrow")) return rc;
     hipLaunchKernelGGL(prior_vrow_kernel, grid, dim3(kPgWaves * 64), lds, as_stream(stream), d, M, N);
     return check_launch("prior_vrow");
@@ -854,7 +855,7 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
     }
     const int upb = dtype == DVQ_F32 ? 4 : 2;
     // k-blocks of 32 features per LDS stage (an fp32 stage of one block is as large as a bf16 stage of two)
-    const int ks = (dtype == DVQ_F32 || M >= 4096) ? 1 : 2;
+    const int ks = dtype == DVQ_F32 ? 1 : 2;
     for (int j = 0; j < n_jobs; ++j)
         for (int t = 0; t < jobs[j].n_taps; ++t)
             if (jobs[j].taps[t].k_blocks % 2) return fail(DVQ_EINVAL, "prior_gemm: k_blocks must be even");
@@ -877,9 +878,7 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
         if (dtype == DVQ_F32) {                                            \
             if (no == 4) DVQ_PG_LAUNCH3(DVQ_F32, E, 4, 1);                 \
             else DVQ_PG_LAUNCH3(DVQ_F32, E, 2, 1);                         \
-        } else if (no == 4 && ks == 1) DVQ_PG_LAUNCH3(DVQ_BF16, E, 4, 1);  \
-        else if (no == 4) DVQ_PG_LAUNCH3(DVQ_BF16, E, 4, 2);               \
-        else if (ks == 1) DVQ_PG_LAUNCH3(DVQ_BF16, E, 2, 1);               \
+        } else if (no == 4) DVQ_PG_LAUNCH3(DVQ_BF16, E, 4, 2);             \
         else DVQ_PG_LAUNCH3(DVQ_BF16, E, 2, 2);                            \
     } while (0)
     if (epilogue == PG_PACK) DVQ_PG_LAUNCH(PG_PACK);

@@ -42,7 +42,7 @@ class _HostStagedGather:
 
     torch's own gloo path for device tensors stages through a fresh HIGH-PRIORITY pool stream per collective.  On
     this ROCm stack such a stream, made to wait for an event of a stream that is still busy with the generation
-    step's work (prior chain beside the second encoder on a side stream), sometimes never drains -- reproducible
+    step's work (when first seen: the prior's replayed graph beside an encoder on a second stream), sometimes never drains -- reproducible
     in one process without any process group (tools/gloo_hang_probe.py emu1); the same wait on a normal-priority
     pool stream (what the RCCL backend uses), or on a high-priority stream that has been used before, completes.
     Staging on the caller's stream takes that stream out of the picture."""

@@ -1,6 +1,6 @@
 """The configuration the benchmark times -- 4096 object clouds x 3000 points through GraspGenerator.generate, fp32 and
-bf16 -- under parity: the branches only large batches take (the fused vertical-row prior kernel from 3072 rows, the
-second encoder on a side stream from 64, bf16 heads from 512, HIP-graph replay of the prior at that batch size) run
+bf16 -- under parity: the branches only large batches take (the fused vertical-row prior kernel from 3072 rows, one
+launch per encoder stage from 64, bf16 heads from 512, HIP-graph replay of the prior at that batch size) run
 together here and are checked against the CPU oracle and against small-batch runs of the same objects.
 Reference path: DVQ-VAE/network/gen_net.py:78-125 + gen_diverse_grasp_obman.py:243-253."""
 import pytest
@@ -55,7 +55,7 @@ def test_full_batch_teacher_forced_rows_vs_oracle(setup, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_full_batch_sampled_equals_small_batches(setup, dtype):
     """generate(obj)[s] against generate(obj[s]) for slices of fewer than 64 objects: the large batch takes the fused
-    row kernel, the side stream, the bf16 heads and the graph recorded for 4096 rows; the small ones take per-cell
+    row kernel, ungrouped encoder launches, the bf16 heads and the graph recorded for 4096 rows; the small ones take per-cell
     launches, grouped encoders and fp32 heads.  Uniforms are keyed by global object id, so the draws are the same."""
     gen, obj, sd = setup
     dvq_hip.set_compute_dtype(gen.model, dtype)

@@ -210,18 +210,17 @@ def gen():
 
 
 def gen4096():
-    """The bench step (4096 objects, bf16) with the prior's input-free part once per class / once per row."""
+    """The bench step (4096 objects, bf16): position encoder beside the prior (own stream) or before it."""
     from dvq_hip.pipeline import GraspGenerator
     g = GraspGenerator.synthetic(dev, seed=0, dtype=torch.bfloat16)
     obj = synth.object_clouds_device(4096, 3000, 11, dev)
-    pr = g.model.GatedPixelCNN
     ref = None
-    for on in (False, True, False, True):
-        pr.class_rows = on
+    for on in (True, False, True, False):
+        g.model.overlap_pos_encoder = on
         ms = timeit(lambda: g.generate(obj), iters=10, warm=3)
         out = g.generate(obj)["vertices"]
         ref = out if ref is None else ref
-        print(f"generate B=4096 bf16 per class={int(on)}: {ms:8.3f} ms  {4096 / ms * 1e3:10.0f} grasps/s   "
+        print(f"generate B=4096 bf16 encoder beside the prior={int(on)}: {ms:8.3f} ms  {4096 / ms * 1e3:10.0f} grasps/s   "
               f"max |dv| vs first {(out - ref).abs().max().item():.3g}", flush=True)
 
 
