@@ -163,8 +163,9 @@ def prior_roofline(gen, B, device, iters=20):
             "achieved": round(ach, 1), "peak": PEAK_L2_LDS_GBS, "unit": "GB/s", "frac": round(ach / PEAK_L2_LDS_GBS, 4),
             "traffic": None, "avg_launch_ms": round(ms, 5), "launches_timed": iters, "l2_to_lds_bytes_per_launch": l2_bytes,
             "tflops": round(flops / ms / 1e9, 1), "frac_mfma_peak": round(flops / ms / 1e9 / PEAK_TFLOPS["bf16"], 4),
-            "note": "launched back to back outside the replayed graph; 135 such launches + 135 residual 1x1 products + "
-                    "45 vertical-row launches make one grid batch"}
+            "note": "launched back to back outside the replayed graph (independent launches: no dependent-chain stalls); "
+                    "120 such launches + 120 residual 1x1 products + 30 vertical-row launches make one grid batch "
+                    "(grid row 0's vertical stack and cell (0,0) are per-class constants of the weights)"}
 
 
 def cpu_baseline(with_prior, reps=10, batch=16):
