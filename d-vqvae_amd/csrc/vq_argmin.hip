@@ -501,31 +501,56 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_rot_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // one group of 32 codes against the four slots
-    auto code_tile = [&](const char* tb, int base32) {
+    // One group of 32 codes (two halves of 16) against the four slots, laid out so that one wave by itself keeps the
+    // matrix pipe fed: the 2 x S code fragments are read from LDS one item ahead of the four matrix instructions that
+    // use them, and the compare-selects that fold a finished half into the running winners (16 per half) are dealt
+    // two at a time to the items of the NEXT half -- the second half of a group is folded under the first half of
+    // the following group (`pend`), the last one of a stage by flush_pending().  Halves are folded in code order.
+    f32x4 pend[NB];
+    int pend_base = 0;
+    auto fold_two = [&](const f32x4 (&a)[NB], int base, int pair) {
+#pragma unroll
+        for (int j = 2 * pair; j < 2 * pair + 2; ++j) {   // codes increase with i: '>' keeps the lowest index among equals
+            const int nb = j >> 2, i = j & 3;
+            const float v = a[nb][i];
+            const bool gt = v > best[nb];
+            bidx[nb] = gt ? base + i : bidx[nb];
+            best[nb] = gt ? v : best[nb];
+        }
+    };
+    auto flush_pending = [&]() {
+#pragma unroll
+        for (int pair = 0; pair < 2 * NB; ++pair) fold_two(pend, pend_base, pair);
+    };
+    auto code_tile = [&](auto has_pending, const char* tb, int base32) {
+        constexpr bool PEND = decltype(has_pending)::value;
+        static_assert(S == 2 * NB, "two compare-selects per item cover a half exactly when S == 2 * NB");
+        f32x4 acc[2][NB];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const f32x4 e = *reinterpret_cast<const f32x4*>(tb + 2 * S * 1024 + (16 * hh + 4 * q) * 4);
-            const int base = base32 + 16 * hh + 4 * q;
-            f32x4 acc[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = e;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(tb + (hh * S + s) * 1024 + lane * 16);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, zb[nb][s], acc[nb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {   // codes increase with i: '>' keeps the lowest index among equals
-                    const float v = acc[nb][i];
-                    const bool gt = v > best[nb];
-                    bidx[nb] = gt ? base + i : bidx[nb];
-                    best[nb] = gt ? v : best[nb];
-                }
+            for (int nb = 0; nb < NB; ++nb) acc[hh][nb] = e;
         }
+        bf16x8 a[2];
+        a[0] = *reinterpret_cast<const bf16x8*>(tb + lane * 16);
+        const int base0 = base32 + 4 * q;
+#pragma unroll
+        for (int item = 0; item < 2 * S; ++item) {
+            const int hh = item / S, s = item % S;
+            if (item + 1 < 2 * S) a[(item + 1) & 1] = *reinterpret_cast<const bf16x8*>(tb + (item + 1) * 1024 + lane * 16);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[hh][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[item & 1], zb[nb][s], acc[hh][nb], 0, 0, 0);
+            if (hh == 0) {
+                if (PEND) fold_two(pend, pend_base, s);
+            } else {
+                fold_two(acc[0], base0, s);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keeps this order: read of item + 1, products of item, two folds
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[1][nb];
+        pend_base = base0 + 16;
     };
 
     int g = 0;               // stages consumed so far; stage g sits in buffer g&1
@@ -565,7 +590,9 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_rot_kernel(
             const int t_count = (n_tiles - t_first) < TS ? (n_tiles - t_first) : TS;
             if (more) issue_stage(cs + 1 == n_stages ? 0 : cs + 1, (g + 1) & 1);
             if (zload) load_tile(p + 1);     // issued after the stage's copies: a counted wait can leave it in flight
-            for (int t = 0; t < t_count; ++t) code_tile(eb + t * TILE_BYTES, (t_first + t) * 32);
+            code_tile(std::false_type{}, eb, t_first * 32);
+            for (int t = 1; t < t_count; ++t) code_tile(std::true_type{}, eb + t * TILE_BYTES, (t_first + t) * 32);
+            flush_pending();
             if (zload) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
