@@ -38,6 +38,7 @@ class GenNet(nn.Module):
         self.recon_encoder = PointNetEncoder(global_feat=True, feature_transform=False, channel=3)
         self.pos_decoder = Decoder(layer_sizes=[1024, 128, 6], latent_size=2048)
         self.GatedPixelCNN = GatedPixelCNN(512, 512, 15)
+        self.together_below = 64               # both object encoders stage by stage in grouped launches below this batch size
 
     def set_rh_mano(self, Rh_mano):
         Rh_mano.eval()
@@ -64,7 +65,7 @@ class GenNet(nn.Module):
         if self.rh_mano is None:
             raise RuntimeError("GenNet.gen: call set_rh_mano(mano_layer) first")
         B = obj.size()[0]
-        together = B < 64 and obj.is_cuda
+        together = B < self.together_below and obj.is_cuda
         if together:
             # small batches: both object encoders stage by stage in grouped launches (each launch alone would leave
             # most of the GPU idle)
