@@ -11,7 +11,7 @@
 //    result independent of the order the points arrive in.
 //  * mano_lbs_backward_kernel -- the vector-Jacobian product of the MANO layer
 //    (DVQ-VAE-2/MANO-master/mano/lbs.py:33-265 differentiated by hand): skinning -> pose blend
-//    shapes -> kinematic chain -> Rodrigues -> PCA, four hands per workgroup.
+//    shapes -> kinematic chain -> Rodrigues -> PCA, sixteen hands per workgroup.
 #include "common.h"
 
 namespace dvq {
@@ -224,324 +224,406 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Vector-Jacobian product of the MANO layer, sixteen hands per workgroup, laid out like the forward kernel
+// (csrc/mano.hip): a lane is (hand = lane & 15, q = lane >> 4) and owns vertices v0 + 4q + i of a group of 16.
+//   1  full pose and Rodrigues, one thread per (hand, joint); 2  kinematic chain, one thread per (hand, matrix row);
+//   3  per vertex group: T_v from the vertex's few non-zero skinning weights, dL/dv_posed = T_v^T g_v in registers,
+//      and at once the B operand of dL/dpose_feature = posedirs . dL/dv_posed on the 16x16x4 fp32 MFMA (nine tiles of 16
+//      features x 16 hands; k = the four vertices v0 + 4q + i of the lanes' q, one coordinate per instruction) --
+//      posedirs is read once per workgroup, 12 B per lane, a group ahead; the four waves' partial tiles meet in LDS and
+//      are summed in wave order;
+//   4  dL/dA_j = sum_v w_vj g_v [v_posed_v; 1]^T, one thread per (hand, joint), vertices in ascending order;
+//   5  chain backward: the part that climbs the tree works on rows (row a of dG_parent needs row a of dG_child only),
+//      one thread per (hand, row); then per (hand, joint) dL/dR_j, Rodrigues backward and the PCA projection.
+// Every sum has a fixed order: the result does not depend on launch geometry or timing.
 constexpr int kBwJ = 16;
 constexpr int kBwPF = 135;
-constexpr int kBwHB = 4;        // hands per workgroup: every posedirs element fetched feeds kBwHB multiply-adds
-constexpr int kBwSlices = kTtaThreads / kBwJ;   // vertex slices of the dL/dA reduction
+constexpr int kBwHB = 16;                 // hands per workgroup
+constexpr int kBwPT = 9;                  // tiles of 16 pose features (135 -> 144)
+constexpr int kBwSkinW = 8;               // slots per vertex in the skinning table (as in csrc/mano.hip)
+
+struct bw3 { float x, y, z; };
 
 struct BwShared {
-    float Rv[kBwHB][kBwJ][3];      // full pose (axis-angle per joint)
     float R[kBwHB][kBwJ][9];
-    float T[kBwHB][kBwJ][12];      // world transforms
-    float A[kBwHB][kBwJ][12];      // skinning transforms
+    float Ap[kBwHB][kBwJ * 12 + 4];      // skinning transforms; padded against bank conflicts of the per-hand gather
+    float T[kBwHB][kBwJ][12];            // world transforms
+    float Rv[kBwHB][kBwJ][3];            // full pose (axis-angle per joint)
     float dA[kBwHB][kBwJ][12];
-    float dPF[kBwHB][kBwPF + 1];
     float dGR[kBwHB][kBwJ][9];
     float dGt[kBwHB][kBwJ][3];
-    float dR[kBwHB][kBwJ][9];
+    float dPF[kBwHB][kBwPT * 16];
     float dPose[kBwHB][48];
-    float Tr[kBwHB][kTtaWaves][3];
+    float part[kTtaWaves][kBwPT][4][64]; // per-wave partial tiles of dL/dpose_feature
+    float Tr[kTtaWaves][kBwHB][3];       // per-wave partial sums of g (= dL/dtransl)
+    float HP[kBwHB][48];
+    float Comps[45 * 45];
+    float J[kBwJ * 3];
+    int Par[kBwJ];
 };
 
-__global__ __launch_bounds__(kTtaThreads, 2) void mano_lbs_backward_kernel(
+template <bool TABLE>
+__global__ __launch_bounds__(kTtaThreads) void mano_lbs_backward_kernel(
     const float* __restrict__ global_orient, const float* __restrict__ hand_pose, int B, int V, int ncomp,
     const float* __restrict__ joints, const float* __restrict__ posedirs, const float* __restrict__ weights,
     const float* __restrict__ comps, const float* __restrict__ pose_mean, const int* __restrict__ parents,
+    const unsigned char* __restrict__ skin_joints, const float* __restrict__ skin_weights,
     const float* __restrict__ v_posed, const float* __restrict__ grad_verts, float* __restrict__ g_orient,
     float* __restrict__ g_pose, float* __restrict__ g_transl) {
     extern __shared__ __attribute__((aligned(16))) char bw_smem[];
-    // [kBwHB][3V] dL/dv_posed; before it is filled the same memory holds the per-wave partial sums of dL/dA
-    float* sDVP = reinterpret_cast<float*>(bw_smem);
-    float* sPart = sDVP;                                  // [kBwHB][waves][16][12]
-    __shared__ BwShared sh;
+    BwShared& sh = *reinterpret_cast<BwShared*>(bw_smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * kBwHB;
     const int nh = (B - b0) < kBwHB ? (B - b0) : kBwHB;
-    const int V3 = 3 * V;
+    const int64_t V3 = 3 * (int64_t)V;
 
-    // ---- forward pieces needed again: full pose, rotations   (lbs.py:167-198)
-    if (tid < kBwHB * kBwJ && tid / kBwJ < nh) {
-        const int h = tid / kBwJ, j = tid % kBwJ, b = b0 + h;
-        float rv[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v;
-            if (j == 0) {
-                v = global_orient[b * 3 + c];
-            } else {
-                const int col = 3 * (j - 1) + c;
-                v = 0.f;
-                for (int i = 0; i < ncomp; ++i) v = __builtin_fmaf(hand_pose[b * ncomp + i], comps[i * 45 + col], v);
-            }
-            v += pose_mean[3 * j + c];
-            rv[c] = v;
-            sh.Rv[h][j][c] = v;
-        }
-        const float ax = rv[0] + 1e-8f, ay = rv[1] + 1e-8f, az = rv[2] + 1e-8f;
-        const float angle = sqrtf(ax * ax + ay * ay + az * az);
-        const float rx = rv[0] / angle, ry = rv[1] / angle, rz = rv[2] / angle;
-        const float cs = cosf(angle), sn = sinf(angle);
-        const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
-        const float omc = 1.f - cs;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
+    for (int i = tid; i < nh * ncomp; i += kTtaThreads) sh.HP[i / ncomp][i % ncomp] = hand_pose[(int64_t)b0 * ncomp + i];
+    for (int i = tid; i < ncomp * 45; i += kTtaThreads) sh.Comps[i] = comps[i];
+    if (tid < kBwJ * 3) sh.J[tid] = joints[tid];
+    if (tid < kBwJ) sh.Par[tid] = parents[tid];
+    __syncthreads();
+
+    // ---- 1: full pose, rotations   (lbs.py:167-198)
+    {
+        const int h = tid / kBwJ, j = tid % kBwJ;
+        if (h < nh) {
+            const int b = b0 + h;
+            float rv[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float kk = K[a * 3 + 0] * K[0 * 3 + c];
-                kk = __builtin_fmaf(K[a * 3 + 1], K[1 * 3 + c], kk);
-                kk = __builtin_fmaf(K[a * 3 + 2], K[2 * 3 + c], kk);
-                sh.R[h][j][a * 3 + c] = ((a == c ? 1.f : 0.f) + sn * K[a * 3 + c]) + omc * kk;
-            }
-    }
-    __syncthreads();
-    // ---- kinematic chain, one thread per hand   (lbs.py:214-265)
-    if (tid < nh) {
-        const int h = tid;
-        for (int i = 0; i < kBwJ; ++i) {
-            const int par = parents[i];
-            float t[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) t[c] = (i == 0) ? joints[c] : joints[i * 3 + c] - joints[par * 3 + c];
-            float T[12];
-            if (i == 0) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) T[a * 4 + c] = sh.R[h][0][a * 3 + c];
-                    T[a * 4 + 3] = t[a];
+                float v;
+                if (j == 0) {
+                    v = global_orient[b * 3 + c];
+                } else {
+                    const int col = 3 * (j - 1) + c;
+                    v = 0.f;
+                    for (int i = 0; i < ncomp; ++i) v = __builtin_fmaf(sh.HP[h][i], sh.Comps[i * 45 + col], v);
                 }
-            } else {
-                const float* P = sh.T[h][par];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float v = P[a * 4 + 0] * sh.R[h][i][0 * 3 + c];
-                        v = __builtin_fmaf(P[a * 4 + 1], sh.R[h][i][1 * 3 + c], v);
-                        v = __builtin_fmaf(P[a * 4 + 2], sh.R[h][i][2 * 3 + c], v);
-                        T[a * 4 + c] = v;
-                    }
-                    float v = P[a * 4 + 0] * t[0];
-                    v = __builtin_fmaf(P[a * 4 + 1], t[1], v);
-                    v = __builtin_fmaf(P[a * 4 + 2], t[2], v);
-                    T[a * 4 + 3] = v + P[a * 4 + 3];
-                }
+                v += pose_mean[3 * j + c];
+                rv[c] = v;
+                sh.Rv[h][j][c] = v;
             }
-            const float jx = joints[i * 3 + 0], jy = joints[i * 3 + 1], jz = joints[i * 3 + 2];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float v = T[a * 4 + 0] * jx;
-                v = __builtin_fmaf(T[a * 4 + 1], jy, v);
-                v = __builtin_fmaf(T[a * 4 + 2], jz, v);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) sh.T[h][i][a * 4 + c] = T[a * 4 + c];
-                sh.A[h][i][a * 4 + 0] = T[a * 4 + 0]; sh.A[h][i][a * 4 + 1] = T[a * 4 + 1]; sh.A[h][i][a * 4 + 2] = T[a * 4 + 2];
-                sh.A[h][i][a * 4 + 3] = T[a * 4 + 3] - v;
-            }
-        }
-    }
-
-    // ---- dL/dA_j[a][k] = sum_v w_vj g_v[a] [v_posed_v; 1][k]: thread (joint, vertex slice), then slices are summed
-    {
-        const int j = tid & (kBwJ - 1), slice = tid >> 4;
-        const int per = (V + kBwSlices - 1) / kBwSlices;
-        const int v0 = slice * per, v1 = (v0 + per) < V ? (v0 + per) : V;
-#pragma unroll 1
-        for (int h = 0; h < nh; ++h) {
-            const float* g = grad_verts + (int64_t)(b0 + h) * V3;
-            const float* vp = v_posed + (int64_t)(b0 + h) * V3;
-            float acc[12];
-#pragma unroll
-            for (int e = 0; e < 12; ++e) acc[e] = 0.f;
-            for (int v = v0; v < v1; ++v) {
-                const float w = weights[v * kBwJ + j];
-                const float p0 = vp[3 * v], p1 = vp[3 * v + 1], p2 = vp[3 * v + 2];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float wg = w * g[3 * v + a];
-                    acc[a * 4 + 0] = __builtin_fmaf(wg, p0, acc[a * 4 + 0]);
-                    acc[a * 4 + 1] = __builtin_fmaf(wg, p1, acc[a * 4 + 1]);
-                    acc[a * 4 + 2] = __builtin_fmaf(wg, p2, acc[a * 4 + 2]);
-                    acc[a * 4 + 3] += wg;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 12; ++e) {       // the four slices that share a wave
-                float x = acc[e];
-                x += __shfl_xor(x, 16, 64);
-                x += __shfl_xor(x, 32, 64);
-                if (lane < kBwJ) sPart[((h * kTtaWaves + wave) * kBwJ + j) * 12 + e] = x;
-            }
-        }
-    }
-    __syncthreads();
-    for (int o = tid; o < nh * kBwJ * 12; o += kTtaThreads) {
-        const int h = o / (kBwJ * 12), r = o % (kBwJ * 12);
-        float x = 0.f;
-#pragma unroll
-        for (int w = 0; w < kTtaWaves; ++w) x += sPart[(h * kTtaWaves + w) * kBwJ * 12 + r];
-        sh.dA[h][r / 12][r % 12] = x;
-    }
-    __syncthreads();
-
-    // ---- skinning backward, per vertex: verts = T_v [v_posed; 1] + transl, T_v = sum_j w_vj A_j
-#pragma unroll 1
-    for (int h = 0; h < nh; ++h) {
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-        for (int v = tid; v < V; v += kTtaThreads) {
-            float TR[9];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) TR[e] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(weights + v * kBwJ + 4 * q);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            TR[a * 3 + c] = __builtin_fmaf(w[jj], sh.A[h][4 * q + jj][a * 4 + c], TR[a * 3 + c]);
-            }
-            const float* g = grad_verts + ((int64_t)(b0 + h) * V + v) * 3;
-            const float g0 = g[0], g1 = g[1], g2 = g[2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) sDVP[h * V3 + 3 * v + c] = TR[0 * 3 + c] * g0 + TR[1 * 3 + c] * g1 + TR[2 * 3 + c] * g2;
-            t0 += g0; t1 += g1; t2 += g2;
-        }
-        t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
-        if (lane == 0) { sh.Tr[h][wave][0] = t0; sh.Tr[h][wave][1] = t1; sh.Tr[h][wave][2] = t2; }
-    }
-    __syncthreads();
-
-    // ---- dL/dpose_feature[p] = sum_e posedirs[p][e] dv_posed[e]   (lbs.py:99-101), four p per wave and pass
-    for (int p0 = 4 * wave; p0 < kBwPF; p0 += 4 * kTtaWaves) {
-        float acc[4][kBwHB];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int h = 0; h < kBwHB; ++h) acc[u][h] = 0.f;
-        const float* pd[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pd[u] = posedirs + (int64_t)((p0 + u) < kBwPF ? (p0 + u) : (kBwPF - 1)) * V3;
-        for (int e = lane; e < V3; e += 64) {
-            float d[kBwHB];
-#pragma unroll
-            for (int h = 0; h < kBwHB; ++h) d[h] = h < nh ? sDVP[h * V3 + e] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float x = pd[u][e];
-#pragma unroll
-                for (int h = 0; h < kBwHB; ++h) acc[u][h] = __builtin_fmaf(x, d[h], acc[u][h]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int h = 0; h < kBwHB; ++h) {
-                const float x = wave_sum(acc[u][h]);
-                if (lane == 0 && p0 + u < kBwPF) sh.dPF[h][p0 + u] = x;
-            }
-    }
-    __syncthreads();
-
-    // ---- chain backward, one thread per hand (children have larger indices than their parents)
-    if (tid < nh) {
-        const int h = tid;
-        for (int j = 0; j < kBwJ; ++j) {
-            const float jx = joints[j * 3], jy = joints[j * 3 + 1], jz = joints[j * 3 + 2];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {   // A = [G_R | G_t - G_R J]
-                const float dt = sh.dA[h][j][a * 4 + 3];
-                sh.dGR[h][j][a * 3 + 0] = sh.dA[h][j][a * 4 + 0] - dt * jx;
-                sh.dGR[h][j][a * 3 + 1] = sh.dA[h][j][a * 4 + 1] - dt * jy;
-                sh.dGR[h][j][a * 3 + 2] = sh.dA[h][j][a * 4 + 2] - dt * jz;
-                sh.dGt[h][j][a] = dt;
-            }
-        }
-        for (int i = kBwJ - 1; i >= 1; --i) {
-            const int par = parents[i];
-            const float* P = sh.T[h][par];
-            float rel[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rel[c] = joints[i * 3 + c] - joints[par * 3 + c];
-            float dGR[9], dGt[3];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) dGR[e] = sh.dGR[h][i][e];
-#pragma unroll
-            for (int e = 0; e < 3; ++e) dGt[e] = sh.dGt[h][i][e];
-            // G_R,i = G_R,par R_i ; G_t,i = G_R,par rel_i + G_t,par
+            const float ax = rv[0] + 1e-8f, ay = rv[1] + 1e-8f, az = rv[2] + 1e-8f;
+            const float angle = sqrtf(ax * ax + ay * ay + az * az);
+            const float rx = rv[0] / angle, ry = rv[1] / angle, rz = rv[2] / angle;
+            const float cs = cosf(angle), sn = sinf(angle);
+            const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+            const float omc = 1.f - cs;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float dR = P[0 * 4 + a] * dGR[0 * 3 + c] + P[1 * 4 + a] * dGR[1 * 3 + c] + P[2 * 4 + a] * dGR[2 * 3 + c];
-                    sh.dR[h][i][a * 3 + c] = dR + sh.dPF[h][(i - 1) * 9 + a * 3 + c];
-                    sh.dGR[h][par][a * 3 + c] += dGR[a * 3 + 0] * sh.R[h][i][c * 3 + 0] + dGR[a * 3 + 1] * sh.R[h][i][c * 3 + 1] +
-                                                 dGR[a * 3 + 2] * sh.R[h][i][c * 3 + 2] + dGt[a] * rel[c];
+                    float kk = K[a * 3 + 0] * K[0 * 3 + c];
+                    kk = __builtin_fmaf(K[a * 3 + 1], K[1 * 3 + c], kk);
+                    kk = __builtin_fmaf(K[a * 3 + 2], K[2 * 3 + c], kk);
+                    sh.R[h][j][a * 3 + c] = ((a == c ? 1.f : 0.f) + sn * K[a * 3 + c]) + omc * kk;
                 }
+        } else {   // hands past the end of the batch: finite transforms for the gathers of phase 3
 #pragma unroll
-            for (int a = 0; a < 3; ++a) sh.dGt[h][par][a] += dGt[a];
+            for (int e = 0; e < 12; ++e) sh.Ap[h][j * 12 + e] = 0.f;
         }
+    }
+    __syncthreads();
+    // ---- 2: kinematic chain, one thread per (hand, row of the 3x4 transform)   (lbs.py:214-265)
+    if (tid < 3 * nh) {
+        const int h = tid / 3, a = tid % 3;
+        for (int i = 0; i < kBwJ; ++i) {
+            const int par = sh.Par[i];
+            float t[3];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) sh.dR[h][0][e] = sh.dGR[h][0][e];
+            for (int c = 0; c < 3; ++c) t[c] = (i == 0) ? sh.J[c] : sh.J[i * 3 + c] - sh.J[par * 3 + c];
+            float T[4];
+            if (i == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) T[c] = sh.R[h][0][a * 3 + c];
+                T[3] = t[a];
+            } else {
+                const float* P = &sh.T[h][par][a * 4];   // written by this very thread in an earlier step
+                const float p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float v = p0 * sh.R[h][i][0 * 3 + c];
+                    v = __builtin_fmaf(p1, sh.R[h][i][1 * 3 + c], v);
+                    v = __builtin_fmaf(p2, sh.R[h][i][2 * 3 + c], v);
+                    T[c] = v;
+                }
+                float v = p0 * t[0];
+                v = __builtin_fmaf(p1, t[1], v);
+                v = __builtin_fmaf(p2, t[2], v);
+                T[3] = v + p3;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sh.T[h][i][a * 4 + e] = T[e];
+            float v = T[0] * sh.J[i * 3 + 0];
+            v = __builtin_fmaf(T[1], sh.J[i * 3 + 1], v);
+            v = __builtin_fmaf(T[2], sh.J[i * 3 + 2], v);
+            float* A = &sh.Ap[h][i * 12 + a * 4];
+            A[0] = T[0]; A[1] = T[1]; A[2] = T[2];
+            A[3] = T[3] - v;
+        }
     }
     __syncthreads();
 
-    // ---- Rodrigues backward, one thread per (hand, joint)
-    if (tid < kBwHB * kBwJ && tid / kBwJ < nh) {
-        const int h = tid / kBwJ, j = tid % kBwJ;
-        const float vx = sh.Rv[h][j][0], vy = sh.Rv[h][j][1], vz = sh.Rv[h][j][2];
-        const float ex = vx + 1e-8f, ey = vy + 1e-8f, ez = vz + 1e-8f;
-        const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
-        const float inv = 1.f / ang;
-        const float nx = vx * inv, ny = vy * inv, nz = vz * inv;
-        const float cs = cosf(ang), sn = sinf(ang), omc = 1.f - cs;
-        const float K[9] = {0.f, -nz, ny, nz, 0.f, -nx, -ny, nx, 0.f};
-        float KK[9], dR[9];
+    // ---- 3: skinning backward and the pose blend-shape product, per group of 16 vertices
+    {
+        const int h = lane & 15, q = lane >> 4;
+        const int hc = h < nh ? h : 0;                         // surplus lanes repeat hand 0 with zero gradient
+        const int n_groups = (V + 15) / 16;
+        constexpr int NSLOT = TABLE ? kBwSkinW : kBwJ;
+        f32x4 acc[kBwPT];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int t = 0; t < kBwPT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
+        // A operand of group g: pose feature 16t + (lane & 15), vertex 16g + 4q + i: the three coordinates as one 12-byte
+        // load.  Features 135..143 do not exist: their rows are clamped to 134 and never read back.
+        bw3 afrag[kBwPT][4];
+        auto load_group_slot = [&](int g, int i) {
+            int v = 16 * g + 4 * q + i;
+            if (v >= V) v = V - 1;
+#pragma unroll
+            for (int t = 0; t < kBwPT; ++t) {
+                const int pf = (16 * t + h) < kBwPF ? (16 * t + h) : kBwPF - 1;
+                afrag[t][i] = *reinterpret_cast<const bw3*>(posedirs + pf * V3 + 3 * (int64_t)v);
+            }
+        };
+        auto load_group = [&](int g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_group_slot(g, i);
+        };
+        // gradients and skinning slots of this lane's four vertices of a group
+        struct Small {
+            bw3 gv[4];
+            f32x4 sw[4][NSLOT / 4];
+            uint2 sj[4];
+        };
+        auto load_small = [&](int g, Small& m) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int v = 16 * g + 4 * q + i;
+                if (v >= V) v = V - 1;
+                m.gv[i] = *reinterpret_cast<const bw3*>(grad_verts + ((int64_t)(b0 + hc) * V + v) * 3);
+#pragma unroll
+                for (int c = 0; c < NSLOT / 4; ++c)
+                    m.sw[i][c] = *reinterpret_cast<const f32x4*>((TABLE ? skin_weights : weights) + (int64_t)v * NSLOT + 4 * c);
+                if (TABLE) m.sj[i] = *reinterpret_cast<const uint2*>(skin_joints + (int64_t)v * kBwSkinW);
+            }
+        };
+        // One wave per SIMD: nothing else hides a load, so everything a group needs is requested a group ahead -- the
+        // small per-vertex data before the previous group's matrix instructions, the A fragments of vertex slot i as
+        // soon as the previous group's instructions on slot i are through.
+        Small cur, nxt;
+        if (wave < n_groups) {
+            load_group(wave);
+            if (TABLE) load_small(wave, cur);
+        }
+        for (int g = wave; g < n_groups; g += kTtaWaves) {
+            const int v0 = 16 * g;
+            const bool more = g + kTtaWaves < n_groups;
+            if (!TABLE) load_small(g, cur);   // (the dense matrix: 64 weights per lane, no room to hold two groups)
+            int n_slots = NSLOT;
+            if (TABLE) {   // table slots are non-zero first: what any lane of the wave still needs bounds the loop
+                n_slots = 0;
+#pragma unroll
+                for (int e = 0; e < kBwSkinW; ++e) {
+                    const bool any = cur.sw[0][e / 4][e % 4] != 0.f || cur.sw[1][e / 4][e % 4] != 0.f || cur.sw[2][e / 4][e % 4] != 0.f ||
+                                     cur.sw[3][e / 4][e % 4] != 0.f;
+                    if (__ballot(any) != 0) n_slots = e + 1;
+                }
+            }
+            float dvp[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool live = (v0 + 4 * q + i) < V && h < nh;
+                const float gx = live ? cur.gv[i].x : 0.f, gy = live ? cur.gv[i].y : 0.f, gz = live ? cur.gv[i].z : 0.f;
+                float TR[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) TR[e] = 0.f;
+#pragma unroll
+                for (int e = 0; e < NSLOT; ++e) {
+                    if (e >= n_slots) break;
+                    const int j = TABLE ? (int)(((e < 4 ? cur.sj[i].x : cur.sj[i].y) >> (8 * (e & 3))) & 15u) : e;
+                    const float w = cur.sw[i][e / 4][e % 4];
+                    const float* A = &sh.Ap[h][j * 12];
+                    const f32x4 A0 = *reinterpret_cast<const f32x4*>(A);
+                    const f32x4 A1 = *reinterpret_cast<const f32x4*>(A + 4);
+                    const f32x4 A2 = *reinterpret_cast<const f32x4*>(A + 8);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        TR[c] = __builtin_fmaf(w, A0[c], TR[c]);
+                        TR[3 + c] = __builtin_fmaf(w, A1[c], TR[3 + c]);
+                        TR[6 + c] = __builtin_fmaf(w, A2[c], TR[6 + c]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dvp[i][c] = TR[0 * 3 + c] * gx + TR[1 * 3 + c] * gy + TR[2 * 3 + c] * gz;
+                tr0 += gx; tr1 += gy; tr2 += gz;
+            }
+            if (TABLE && more) load_small(g + kTtaWaves, nxt);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int t = 0; t < kBwPT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][i].x, dvp[i][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][i].y, dvp[i][1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][i].z, dvp[i][2], acc[t], 0, 0, 0);
+                }
+                if (more) load_group_slot(g + kTtaWaves, i);
+            }
+            if (TABLE) cur = nxt;
+        }
+        // accumulator: lane (hand h, row group q), register i <-> pose feature 16t + 4q + i
+#pragma unroll
+        for (int t = 0; t < kBwPT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sh.part[wave][t][i][lane] = acc[t][i];
+        tr0 += __shfl_xor(tr0, 16, 64); tr0 += __shfl_xor(tr0, 32, 64);
+        tr1 += __shfl_xor(tr1, 16, 64); tr1 += __shfl_xor(tr1, 32, 64);
+        tr2 += __shfl_xor(tr2, 16, 64); tr2 += __shfl_xor(tr2, 32, 64);
+        if (q == 0) { sh.Tr[wave][h][0] = tr0; sh.Tr[wave][h][1] = tr1; sh.Tr[wave][h][2] = tr2; }
+    }
+    __syncthreads();
+    for (int o = tid; o < kBwPT * 4 * 64; o += kTtaThreads) {
+        const int l = o & 63, i = (o >> 6) & 3, t = o >> 8;
+        float x = sh.part[0][t][i][l];
+#pragma unroll
+        for (int w = 1; w < kTtaWaves; ++w) x += sh.part[w][t][i][l];
+        sh.dPF[l & 15][16 * t + 4 * (l >> 4) + i] = x;
+    }
+
+    // ---- 4: dL/dA_j[a][k] = sum_v w_vj g_v[a] [v_posed_v; 1][k]: per hand a [16 joints x V] x [V x 12] product on the
+    // 16x16x4 MFMA, a wave per hand.  A = weights^T (4 vertices x 16 joints: 256 contiguous bytes of the dense matrix),
+    // B = the outer product g_v (x) [v_posed_v; 1] formed on the lane: column c <-> (a, k) = (c / 4, c % 4), 12 of 16 used.
+    {
+        const int c = lane & 15, kq = lane >> 4;
+        const int ca = c >> 2, ck = c & 3;
+        for (int hh = wave; hh < nh; hh += kTtaWaves) {
+            const float* g = grad_verts + (int64_t)(b0 + hh) * V3;
+            const float* vp = v_posed + (int64_t)(b0 + hh) * V3;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            constexpr int U = 8;                                     // k-steps whose operands are requested together
+            float w[U], ga[U], pk[U], wn[U], gan[U], pkn[U];
+            auto fetch = [&](int v0, float (&ww)[U], float (&gg)[U], float (&pp)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int v = v0 + 4 * u + kq;
+                    if (v >= V) v = V - 1;
+                    ww[u] = weights[v * kBwJ + c];                   // A: joint c of vertex v
+                    gg[u] = g[3 * v + (ca < 3 ? ca : 0)];
+                    pp[u] = ck < 3 ? vp[3 * v + ck] : 1.f;
+                }
+            };
+            fetch(0, w, ga, pk);
+            for (int v0 = 0; v0 < V; v0 += 4 * U) {
+                if (v0 + 4 * U < V) fetch(v0 + 4 * U, wn, gan, pkn);   // the next batch, under this batch's products
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool in = (v0 + 4 * u + kq) < V;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(in ? w[u] : 0.f, (in && c < 12) ? ga[u] * pk[u] : 0.f, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { w[u] = wn[u]; ga[u] = gan[u]; pk[u] = pkn[u]; }
+            }
+            // lane (column c, row group kq), register i <-> joint 4 kq + i
+            if (c < 12) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sh.dA[hh][4 * kq + i][c] = acc[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 5a: chain backward, the climb, one thread per (hand, row)   A = [G_R | G_t - G_R J]
+    if (tid < 3 * nh) {
+        const int h = tid / 3, a = tid % 3;
+        for (int j = 0; j < kBwJ; ++j) {
+            const float dt = sh.dA[h][j][a * 4 + 3];
+            sh.dGR[h][j][a * 3 + 0] = sh.dA[h][j][a * 4 + 0] - dt * sh.J[j * 3 + 0];
+            sh.dGR[h][j][a * 3 + 1] = sh.dA[h][j][a * 4 + 1] - dt * sh.J[j * 3 + 1];
+            sh.dGR[h][j][a * 3 + 2] = sh.dA[h][j][a * 4 + 2] - dt * sh.J[j * 3 + 2];
+            sh.dGt[h][j][a] = dt;
+        }
+        // G_R,i = G_R,par R_i ; G_t,i = G_R,par rel_i + G_t,par   (children have larger indices than their parents)
+        for (int i = kBwJ - 1; i >= 1; --i) {
+            const int par = sh.Par[i];
+            const float r0 = sh.dGR[h][i][a * 3 + 0], r1 = sh.dGR[h][i][a * 3 + 1], r2 = sh.dGR[h][i][a * 3 + 2];
+            const float dgt = sh.dGt[h][i][a];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                KK[a * 3 + c] = K[a * 3 + 0] * K[0 * 3 + c] + K[a * 3 + 1] * K[1 * 3 + c] + K[a * 3 + 2] * K[2 * 3 + c];
-                dR[a * 3 + c] = sh.dR[h][j][a * 3 + c];
+                const float rel = sh.J[i * 3 + c] - sh.J[par * 3 + c];
+                sh.dGR[h][par][a * 3 + c] += r0 * sh.R[h][i][c * 3 + 0] + r1 * sh.R[h][i][c * 3 + 1] + r2 * sh.R[h][i][c * 3 + 2] + dgt * rel;
             }
-        float dS = 0.f, dO = 0.f;
+            sh.dGt[h][par][a] += dgt;
+        }
+    }
+    __syncthreads();
+
+    // ---- 5b: dL/dR_j and Rodrigues backward, one thread per (hand, joint)
+    {
+        const int h = tid / kBwJ, j = tid % kBwJ;
+        if (h < nh) {
+            float dR[9];
+            if (j == 0) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) { dS += dR[e] * K[e]; dO += dR[e] * KK[e]; }
-        float dK[9];
+                for (int e = 0; e < 9; ++e) dR[e] = sh.dGR[h][0][e];
+            } else {
+                const float* P = sh.T[h][sh.Par[j]];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+                for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                float t = 0.f;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) t += dR[p * 3 + m] * K[q * 3 + m] + K[m * 3 + p] * dR[m * 3 + q];
-                dK[p * 3 + q] = sn * dR[p * 3 + q] + omc * t;
+                    for (int c = 0; c < 3; ++c)
+                        dR[a * 3 + c] = (P[0 * 4 + a] * sh.dGR[h][j][0 * 3 + c] + P[1 * 4 + a] * sh.dGR[h][j][1 * 3 + c] +
+                                         P[2 * 4 + a] * sh.dGR[h][j][2 * 3 + c]) + sh.dPF[h][(j - 1) * 9 + a * 3 + c];
             }
-        const float dnx = dK[2 * 3 + 1] - dK[1 * 3 + 2];
-        const float dny = dK[0 * 3 + 2] - dK[2 * 3 + 0];
-        const float dnz = dK[1 * 3 + 0] - dK[0 * 3 + 1];
-        float da = cs * dS + sn * dO;
-        da -= (dnx * vx + dny * vy + dnz * vz) * inv * inv;
-        sh.dPose[h][3 * j + 0] = dnx * inv + da * ex * inv;
-        sh.dPose[h][3 * j + 1] = dny * inv + da * ey * inv;
-        sh.dPose[h][3 * j + 2] = dnz * inv + da * ez * inv;
+            const float vx = sh.Rv[h][j][0], vy = sh.Rv[h][j][1], vz = sh.Rv[h][j][2];
+            const float ex = vx + 1e-8f, ey = vy + 1e-8f, ez = vz + 1e-8f;
+            const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
+            const float inv = 1.f / ang;
+            const float nx = vx * inv, ny = vy * inv, nz = vz * inv;
+            const float cs = cosf(ang), sn = sinf(ang), omc = 1.f - cs;
+            const float K[9] = {0.f, -nz, ny, nz, 0.f, -nx, -ny, nx, 0.f};
+            float KK[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    KK[a * 3 + c] = K[a * 3 + 0] * K[0 * 3 + c] + K[a * 3 + 1] * K[1 * 3 + c] + K[a * 3 + 2] * K[2 * 3 + c];
+            float dS = 0.f, dO = 0.f;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { dS += dR[e] * K[e]; dO += dR[e] * KK[e]; }
+            float dK[9];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) t += dR[p * 3 + m] * K[qq * 3 + m] + K[m * 3 + p] * dR[m * 3 + qq];
+                    dK[p * 3 + qq] = sn * dR[p * 3 + qq] + omc * t;
+                }
+            const float dnx = dK[2 * 3 + 1] - dK[1 * 3 + 2];
+            const float dny = dK[0 * 3 + 2] - dK[2 * 3 + 0];
+            const float dnz = dK[1 * 3 + 0] - dK[0 * 3 + 1];
+            float da = cs * dS + sn * dO;
+            da -= (dnx * vx + dny * vy + dnz * vz) * inv * inv;
+            sh.dPose[h][3 * j + 0] = dnx * inv + da * ex * inv;
+            sh.dPose[h][3 * j + 1] = dny * inv + da * ey * inv;
+            sh.dPose[h][3 * j + 2] = dnz * inv + da * ez * inv;
+        }
     }
     __syncthreads();
 
     if (tid < nh * 3) {
         const int h = tid / 3, c = tid % 3, b = b0 + h;
         if (g_orient) g_orient[b * 3 + c] = sh.dPose[h][c];
-        if (g_transl) g_transl[b * 3 + c] = ((sh.Tr[h][0][c] + sh.Tr[h][1][c]) + sh.Tr[h][2][c]) + sh.Tr[h][3][c];
+        if (g_transl) g_transl[b * 3 + c] = ((sh.Tr[0][h][c] + sh.Tr[1][h][c]) + sh.Tr[2][h][c]) + sh.Tr[3][h][c];
     }
     if (g_pose) {   // pose = coefficients x components (model.py:330-331)
         for (int o = tid; o < nh * ncomp; o += kTtaThreads) {
             const int h = o / ncomp, c = o % ncomp;
             float acc = 0.f;
-            for (int m = 0; m < 45; ++m) acc = __builtin_fmaf(comps[c * 45 + m], sh.dPose[h][3 + m], acc);
-            g_pose[(b0 + h) * ncomp + c] = acc;
+            for (int m = 0; m < 45; ++m) acc = __builtin_fmaf(sh.Comps[c * 45 + m], sh.dPose[h][3 + m], acc);
+            g_pose[(int64_t)(b0 + h) * ncomp + c] = acc;
         }
     }
 }
@@ -561,13 +643,22 @@ extern "C" int dvq_mano_lbs_backward(const float* global_orient, const float* ha
     if (!m->joints || !m->posedirs || !m->lbs_weights || !m->components || !m->pose_mean || !m->parents)
         return fail(DVQ_EINVAL, "mano_backward: null constant table");
     if (((uintptr_t)m->lbs_weights & 15) != 0) return fail(DVQ_EINVAL, "mano_backward: lbs_weights must be 16-byte aligned");
-    size_t lds = (size_t)kBwHB * 3 * m->n_verts * sizeof(float);
-    const size_t part = (size_t)kBwHB * kTtaWaves * kBwJ * 12 * sizeof(float);
-    if (lds < part) lds = part;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mano_lbs_backward_kernel), lds, "mano_lbs_backward")) return rc;
-    hipLaunchKernelGGL(mano_lbs_backward_kernel, dim3((B + kBwHB - 1) / kBwHB), dim3(kTtaThreads), lds, as_stream(stream), global_orient, hand_pose, B,
-                       m->n_verts, m->n_comps, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean, m->parents,
-                       v_posed, grad_verts, grad_global_orient, grad_hand_pose, grad_transl);
+    const bool table = m->skin_joints != nullptr;
+    if (table && (!m->skin_weights || m->skin_width != kBwSkinW || ((uintptr_t)m->skin_joints & 7) || ((uintptr_t)m->skin_weights & 15)))
+        return fail(DVQ_EINVAL, "mano_backward: the skinning table needs skin_weights, skin_width == %d and aligned arrays", kBwSkinW);
+    const size_t lds = sizeof(BwShared);
+    const dim3 grid((B + kBwHB - 1) / kBwHB), blk(kTtaThreads);
+    if (table) {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mano_lbs_backward_kernel<true>), lds, "mano_lbs_backward")) return rc;
+        hipLaunchKernelGGL(mano_lbs_backward_kernel<true>, grid, blk, lds, as_stream(stream), global_orient, hand_pose, B, m->n_verts,
+                           m->n_comps, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean, m->parents, m->skin_joints,
+                           m->skin_weights, v_posed, grad_verts, grad_global_orient, grad_hand_pose, grad_transl);
+    } else {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mano_lbs_backward_kernel<false>), lds, "mano_lbs_backward")) return rc;
+        hipLaunchKernelGGL(mano_lbs_backward_kernel<false>, grid, blk, lds, as_stream(stream), global_orient, hand_pose, B, m->n_verts,
+                           m->n_comps, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean, m->parents, nullptr,
+                           nullptr, v_posed, grad_verts, grad_global_orient, grad_hand_pose, grad_transl);
+    }
     return check_launch("mano_lbs_backward");
 }
 
