@@ -350,8 +350,8 @@ def main():
                                   "traffic_note": "HBM bytes per launch from separate PMC passes (profiles/r2c_pmc_fetch_write.txt), "
                                                   "not from this run; algorithmic bytes 2.134e8",
                                   "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
-                                  # half of the launches share the GPU with the prior running on the other stream; the
-                                  # launches that had it to themselves (first object encoder) for comparison
+                                  # launches issued on the caller's own stream (all of them since generation became
+                                  # single-stream; earlier builds ran half of them beside the prior on a second stream)
                                   "avg_launch_ms_uncontended": None if alone_ms is None else round(alone_ms, 4),
                                   "frac_uncontended": None if alone_ms is None else round(flops / alone_ms / 1e9 / PEAK_TFLOPS[args.dtype], 4),
                                   "flop_per_launch": flops}
