@@ -153,7 +153,7 @@ class GraspRefiner:
                 for t, s in zip(st["p"] + st["buf"], saved):
                     t.copy_(s)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._step(st)
                 st["graph"] = g
                 for t, s in zip(st["p"] + st["buf"], saved):     # capture does not execute, but keep the state exact

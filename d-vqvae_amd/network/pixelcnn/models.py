@@ -231,10 +231,12 @@ class GatedPixelCNN(nn.Module):
                 parts = [(a, b, self._act_buffers(b - a, H, W, dev, part=(B, k)), torch.cuda.Stream(device=dev))
                          for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
             if parts is None:
+                # (thread-local capture mode: another thread of the process -- the watchdog of a process group polling
+                # its events -- must not invalidate the recording)
                 self._run_hip(bufs, shape, B, None, False, bufs["u"])    # warm-up outside capture
                 torch.cuda.synchronize(dev)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     bufs["x"] = self._run_hip(bufs, shape, B, None, False, bufs["u"])
                 graphs = [g]
             else:
@@ -246,7 +248,7 @@ class GatedPixelCNN(nn.Module):
                     self._run_hip(pb, shape, b - a, None, False, bufs["u"][a:b], x_out=bufs["x"][a:b])
                     torch.cuda.synchronize(dev)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         pb["label"].copy_(bufs["label"][a:b])
                         self._run_hip(pb, shape, b - a, None, False, bufs["u"][a:b], x_out=bufs["x"][a:b])
                     graphs.append(g)
