@@ -333,7 +333,12 @@ def main():
                                    "encoder -> pos decoder) + call-site MANO LBS" +
                                    (f" + {'RCCL' if args.backend == 'nccl' else args.backend} all-gather of vertices" if world > 1 else ""),
                        "objects_per_gpu": B, "points_per_object": N, "global_batch": world * B,
-                       "prior": args.prior, "tta_iterations": args.tta_iters, "weights": "random-init (seed 0), MANO-shaped synthetic hand model",
+                       "prior": args.prior,
+                       "prior_note": "every grid is sampled in full each step; what the sampler computes before its first draw "
+                                     "(vertical stack of grid row 0, cell (0,0)) depends on the class label alone and is a table "
+                                     "of 128 rows computed from the weights, like the packed weights -- no step's inputs or "
+                                     "outputs are cached",
+                       "tta_iterations": args.tta_iters, "weights": "random-init (seed 0), MANO-shaped synthetic hand model",
                        "parallelism": f"dp{world}"},
         }
         if ks is not None:
