@@ -204,7 +204,7 @@ class GatedPixelCNN(nn.Module):
 
         The products run on the HIP kernels of dvq_prior_gemm in `compute_dtype`: float32 (exact fp32, the
         reference's arithmetic) or bfloat16 operands with fp32 accumulation.  With explicit uniforms the whole
-        procedure is a fixed sequence of ~370 launches over persistent buffers; it is captured once per batch
+        procedure is a fixed sequence of ~320 launches over persistent buffers; it is captured once per batch
         size into a HIP graph and replayed, because issuing that many small dependent launches from Python
         costs more than running them."""
         H, W = shape
