@@ -19,7 +19,7 @@
 //   GATE  tanh(y[n]) * sigmoid(y[n+N/2]), y = acc + bias + class_embedding[label]
 //                                                      -> packed bf16 (N/2 features),
 //         optionally also y without the class term     -> packed bf16 (N features)
-//   ROWS  y = acc + bias                               -> fp32 [M, N] row-major (logits)
+//   ROWS  y = acc + bias (relu)                        -> fp32 [M, N] row-major (logits; heads)
 //
 // Tiling: a workgroup of four waves owns NO (4 or 2) output-feature tiles x 4 sample tiles; each
 // wave multiplies all NO weight tiles (shared through LDS) with its own sample tile.
@@ -161,6 +161,10 @@ __device__ __forceinline__ void pg_epilogue(const PgJobDev& job, const Acc& acc,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) y[4 * q4 + q] = acc[t][0][4 * q4 + q] + b[q];
                 if (EPI == PG_ROWS) {
+                    if (relu) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y[4 * q4 + q] = y[4 * q4 + q] > 0.f ? y[4 * q4 + q] : 0.f;
+                    }
                     if (mvalid) {
                         f32x4 o; o[0] = y[4 * q4]; o[1] = y[4 * q4 + 1]; o[2] = y[4 * q4 + 2]; o[3] = y[4 * q4 + 3];
                         *reinterpret_cast<f32x4*>(job.out_rows + (int64_t)m * N + n0) = o;

@@ -505,3 +505,55 @@ def prior_vrow(rows, k_blocks: int, bias, cond, label, out_packed, out_pre, M: i
     with torch.cuda.device(bias.device):
         rc = _lib.load().dvq_prior_vrow(ctypes.byref(v), M, N, _stream(bias))
     _lib.check(rc, "dvq_prior_vrow")
+
+
+# ------------------------------------------------------------------ MLP heads
+# The two wide layers of an MLP head (STN 1024-512-256, decoder 2560-1024-256, position decoder 2048-1024-128) at
+# large batches, bf16 operands: the input pieces are packed once (prior_embed: rows of an fp32 matrix, or codebook
+# rows picked by index -- the concatenation the reference builds is never materialised, each piece is a tap of the
+# first product), the first layer's output stays packed in bf16 (exactly the rounding the second layer's operand
+# load would apply) and the second layer writes fp32 rows.  Same LDS-staged kernel as the prior's products: 2-3x
+# the rate of the register-operand dvq_linear_bf16 at these shapes.
+def head_pack(W0: torch.Tensor, widths, W1: torch.Tensor):
+    """Packed bf16 weights for head_mlp_bf16: W0 [N0, sum(widths)] cut into one block per input piece, W1 [N1, N0]."""
+    offs = [0]
+    for w in widths:
+        offs.append(offs[-1] + w)
+    if offs[-1] != W0.shape[1] or W1.shape[1] != W0.shape[0]:
+        raise RuntimeError("head_pack: piece widths / layer shapes do not chain")
+    W0 = W0.detach().float()
+    return ([prior_pack_weight(W0[:, a:b], DVQ_BF16) for a, b in zip(offs[:-1], offs[1:])], prior_pack_weight(W1.detach().float(), DVQ_BF16),
+            tuple(widths), W0.shape[0], W1.shape[0])
+
+
+def head_shapes_ok(M: int, widths, N0: int, N1: int) -> bool:
+    return (M >= LINEAR_BF16_MIN_ROWS and all(w % 64 == 0 for w in widths) and len(widths) <= 10 and N0 % 128 == 0 and N1 % 128 == 0)
+
+
+def head_mlp_bf16(pieces, packed, b0: torch.Tensor, b1: torch.Tensor, relu1: bool = True) -> torch.Tensor:
+    """relu(relu(cat(pieces) W0^T + b0) W1^T + b1) -> fp32 [M, N1].  A piece is an fp32 [M, d] matrix (unit inner stride)
+    or a pair (idx int64 [M], table fp32 [V, d]) standing for table[idx]."""
+    w0p, w1p, widths, N0, N1 = packed
+    first = pieces[0][0] if isinstance(pieces[0], tuple) else pieces[0]
+    M, dev = first.shape[0], first.device
+    ar = None
+    taps = []
+    for pc, wp, d in zip(pieces, w0p, widths):
+        buf = prior_packed_empty(M, d, dev, False, DVQ_BF16)
+        if isinstance(pc, tuple):
+            idx, table = pc
+            if table.shape[1] != d:
+                raise RuntimeError("head_mlp_bf16: piece width mismatch")
+            prior_embed(idx, table, buf, DVQ_BF16)
+        else:
+            if pc.shape != (M, d) or pc.dtype != torch.float32 or not pc.is_contiguous():
+                raise RuntimeError("head_mlp_bf16: pieces must be contiguous float32 [M, d]")
+            if ar is None:
+                ar = torch.arange(M, dtype=torch.int64, device=dev)
+            prior_embed(ar, pc, buf, DVQ_BF16)
+        taps.append((buf, wp, d // 32))
+    h = prior_packed_empty(M, N0, dev, False, DVQ_BF16)
+    prior_gemm([prior_job(taps, b0, out_packed=h)], M, N0, PRIOR_PACK, True, b0, DVQ_BF16)
+    out = torch.empty(M, N1, dtype=torch.float32, device=dev)
+    prior_gemm([prior_job([(h, w1p, N0 // 32)], b1, out_rows=out)], M, N1, PRIOR_ROWS, relu1, b0, DVQ_BF16)
+    return out

@@ -67,9 +67,30 @@ class Decoder(nn.Module):
         self.compute_dtype = torch.float32
 
     def forward(self, z):
-        x = z.detach()
+        return self.forward_pieces([z.detach()])
+
+    def forward_pieces(self, pieces):
+        """The decoder applied to the concatenation of `pieces` along the feature axis, without building it: a piece is
+        an fp32 [B, d] matrix or a pair (idx int64 [B], table [V, d]) standing for table[idx] (codebook rows).  With
+        bf16 operands, three layers and a large batch the two wide layers run as dvq_hip.ops.head_mlp_bf16."""
         layers = [m for m in self.MLP if isinstance(m, nn.Linear)]
         bf16 = self.compute_dtype == torch.bfloat16
+        first = pieces[0][0] if isinstance(pieces[0], tuple) else pieces[0]
+        widths = [(pc[1] if isinstance(pc, tuple) else pc).shape[1] for pc in pieces]
+        if (bf16 and first.is_cuda and len(layers) == 3
+                and ops.head_shapes_ok(first.shape[0], widths, layers[0].out_features, layers[1].out_features)):
+            W0, W1 = layers[0].weight.detach(), layers[1].weight.detach()
+            key = (W0.data_ptr(), W0._version, W1.data_ptr(), W1._version, tuple(widths))
+            if getattr(self, "_head_key", None) != key:
+                self._head = ops.head_pack(W0, widths, W1)
+                self._head_key = key
+            x = ops.head_mlp_bf16([pc if isinstance(pc, tuple) else pc.detach().contiguous() for pc in pieces], self._head,
+                                  layers[0].bias.detach(), layers[1].bias.detach())
+            return _linear(layers[2], x)
+        xs = []
+        for pc in pieces:
+            xs.append(ops.vq_gather(pc[0].contiguous(), pc[1]) if isinstance(pc, tuple) else pc.detach())
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, 1)
         for i, m in enumerate(layers):
             x = _linear(m, x, relu=(i + 1 < len(layers)), bf16=bf16)
         return x

@@ -48,17 +48,15 @@ class GenNet(nn.Module):
         """codebook rows + object feature -> decoder -> MANO -> recon encoder -> pos decoder
         (gen_net.py:101-123).  part_idx: int64 [B,6]."""
         B = obj_feat_type.shape[0]
-        z_out = torch.empty(B, 2560, dtype=torch.float32, device=obj_feat_type.device)
-        for k in range(6):
-            cb = getattr(self, f"vqvae{k}").vector_quantization.embedding.weight.detach()
-            ops.vq_gather(part_idx[:, k].contiguous(), cb, out=z_out[:, 256 * k:256 * (k + 1)])
-        z_out[:, 1536:] = obj_feat_type        # the un-quantised object feature (gen_net.py:109)
-        recon = self.decoder(z_out).view(B, 55)
+        # six codebook rows and the un-quantised object feature (gen_net.py:109), handed to the decoder piece by piece
+        pieces = [(part_idx[:, k].contiguous(), getattr(self, f"vqvae{k}").vector_quantization.embedding.weight.detach())
+                  for k in range(6)]
+        recon = self.decoder.forward_pieces(pieces + [obj_feat_type]).view(B, 55)
         zero3 = torch.zeros(B, 3, dtype=torch.float32, device=recon.device)
         verts = self.rh_mano(betas=recon[:, :10], global_orient=zero3, hand_pose=recon[:, 10:55].contiguous(),
                              transl=zero3).vertices
         hand_feat, _, _ = self.recon_encoder(verts.detach().permute(0, 2, 1).contiguous())
-        pos = self.pos_decoder(torch.cat((hand_feat, obj_feat_pos), 1)).view(B, 6)
+        pos = self.pos_decoder.forward_pieces([hand_feat, obj_feat_pos]).view(B, 6)
         return recon, pos
 
     def gen(self, obj, x_tilde=None, generator=None, uniforms=None):

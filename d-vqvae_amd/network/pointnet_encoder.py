@@ -79,6 +79,7 @@ class STN3d(nn.Module):
         self.compute_dtype = torch.float32
         self._cache_key = None
         self._cache = None
+        self._head = None
 
     def _packed(self):
         key = (_version_key(self), self.compute_dtype)
@@ -86,7 +87,9 @@ class STN3d(nn.Module):
             trunk = _Trunk(self, _dtype_code(self.compute_dtype))
             f1 = _fold(self.fc1, self.bn4)
             f2 = _fold(self.fc2, self.bn5)
-            if self.compute_dtype == torch.bfloat16:   # bf16 copies of the folded weights for the large-batch kernel
+            self._head = None
+            if self.compute_dtype == torch.bfloat16:   # bf16 copies of the folded weights for the large-batch kernels
+                self._head = ops.head_pack(f1[0], [f1[0].shape[1]], f2[0])
                 f1 = f1 + (ops.to_bf16(f1[0]),)
                 f2 = f2 + (ops.to_bf16(f2[0]),)
             else:
@@ -100,8 +103,11 @@ class STN3d(nn.Module):
         trunk, (w4, b4, w4h), (w5, b5, w5h) = self._packed()
         # conv/bn/relu x3 + max over points (pointnet_encoder.py:29-33)
         g = ops.pointnet_mlp_max(x, None, trunk.as_dict(), True, _dtype_code(self.compute_dtype))
-        g = ops.linear(g, w4, b4, relu=True, W_bf16=w4h)          # fc1+bn4+relu (:35)
-        g = ops.linear(g, w5, b5, relu=True, W_bf16=w5h)          # fc2+bn5+relu (:36)
+        if self._head is not None and ops.head_shapes_ok(g.shape[0], [g.shape[1]], w4.shape[0], w5.shape[0]):
+            g = ops.head_mlp_bf16([g], self._head, b4, b5)        # fc1+bn4+relu, fc2+bn5+relu (:35-36), large batches
+        else:
+            g = ops.linear(g, w4, b4, relu=True, W_bf16=w4h)      # fc1+bn4+relu (:35)
+            g = ops.linear(g, w5, b5, relu=True, W_bf16=w5h)      # fc2+bn5+relu (:36)
         g = ops.linear(g, self.fc3.weight.detach(), self.fc3.bias.detach(), add_identity3=True)  # fc3 + I (:37-43)
         return g.view(-1, 3, 3)
 

@@ -254,7 +254,7 @@ int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, int64_t obj
  *   DVQ_PRIOR_PACK  out_packed = y (+ resid) (relu if `relu`)                      [N features]
  *   DVQ_PRIOR_GATE  out_packed = tanh(u[:N/2]) * sigmoid(u[N/2:]), u = y + cond[label[m]]
  *                   (models.py:25-27, 70-75); out_pre (optional) = y              [N/2], [N]
- *   DVQ_PRIOR_ROWS  out_rows[m, n] = y   (fp32 row-major, the logits)
+ *   DVQ_PRIOR_ROWS  out_rows[m, n] = y (relu if `relu`)   (fp32 row-major: the logits, or the output of an MLP head)
  */
 #define DVQ_PRIOR_PACK 0
 #define DVQ_PRIOR_GATE 1

@@ -206,3 +206,31 @@ def test_pointnet_permutation_and_duplication_invariance():
     assert torch.equal(f0, f1) and torch.equal(t0, t1)
     f2, _, _ = enc(torch.cat([x, x[:, :, :500]], dim=2).contiguous())
     assert torch.equal(f0, f2)
+
+
+def test_head_mlp_bf16_pieces_equal_the_concatenated_input():
+    """The two wide layers of an MLP head on packed bf16 activations (ops.head_mlp_bf16): input pieces given as matrices
+    or as codebook rows picked by index, against the same layers on the concatenated input -- an fp64 evaluation of the
+    bf16-rounded operands (accumulation order is all that may differ) and the register-operand bf16 kernel."""
+    g = torch.Generator(DEV).manual_seed(5)
+    for M in (512, 1000):                      # 1000: not a multiple of the 32-row tile
+        table = torch.randn(128, 256, device=DEV, generator=g)
+        idx = torch.randint(0, 128, (M,), device=DEV, generator=g)
+        a = torch.randn(M, 256, device=DEV, generator=g)
+        b = torch.randn(M, 1024, device=DEV, generator=g)
+        W0 = torch.randn(512, 1536, device=DEV, generator=g) * 0.03
+        b0 = torch.randn(512, device=DEV, generator=g) * 0.1
+        W1 = torch.randn(128, 512, device=DEV, generator=g) * 0.05
+        b1 = torch.randn(128, device=DEV, generator=g) * 0.1
+        assert ops.head_shapes_ok(M, [256, 256, 1024], 512, 128) and not ops.head_shapes_ok(64, [256], 512, 128)
+        packed = ops.head_pack(W0, [256, 256, 1024], W1)
+        got = ops.head_mlp_bf16([(idx, table), a, b], packed, b0, b1)
+        x = torch.cat([table[idx], a, b], 1)
+        r = lambda t: t.to(torch.bfloat16).double()
+        h = torch.relu(r(x) @ r(W0).t() + b0.double()).float()
+        want = torch.relu(r(h) @ r(W1).t() + b1.double())
+        scale = want.abs().max().item()
+        # a hidden value on a bf16 rounding boundary may round the other way under another summation order
+        assert (got.double() - want).abs().max().item() <= 4e-3 * scale
+        old = ops.linear(ops.linear(x, W0, b0, relu=True, W_bf16=ops.to_bf16(W0)), W1, b1, relu=True, W_bf16=ops.to_bf16(W1))
+        assert (got - old).abs().max().item() <= 4e-3 * scale

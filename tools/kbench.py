@@ -119,6 +119,48 @@ def linear():
             print(f"linear M={M_} K={K} N={N} bf16 operands: {ms:.4f} ms  {2.0 * M_ * K * N / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
+def heads():
+    """An MLP head's two wide layers (decoder: 2560 -> 1024 -> 256, 4096 rows, bf16 operands): the register-operand
+    dvq_linear_bf16 kernel against the LDS-staged product kernel of the prior on packed activations."""
+    M_ = 4096
+    g = torch.Generator(dev).manual_seed(0)
+    pieces = [torch.randn(M_, 256, device=dev, generator=g) for _ in range(6)] + [torch.randn(M_, 1024, device=dev, generator=g)]
+    x = torch.cat(pieces, 1).contiguous()
+    W0 = torch.randn(1024, 2560, device=dev, generator=g) * 0.02
+    b0 = torch.randn(1024, device=dev, generator=g) * 0.1
+    W1 = torch.randn(256, 1024, device=dev, generator=g) * 0.03
+    b1 = torch.randn(256, device=dev, generator=g) * 0.1
+    W0b, W1b = ops.to_bf16(W0), ops.to_bf16(W1)
+
+    def old():
+        h = ops.linear(x, W0, b0, relu=True, W_bf16=W0b)
+        return ops.linear(h, W1, b1, relu=True, W_bf16=W1b)
+
+    offs = [0, 256, 512, 768, 1024, 1280, 1536, 2560]
+    W0p = [ops.prior_pack_weight(W0[:, a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    W1p = ops.prior_pack_weight(W1)
+    ar = torch.arange(M_, device=dev)
+
+    def new():
+        taps = []
+        for pc, wp in zip(pieces, W0p):
+            buf = ops.prior_packed_empty(M_, pc.shape[1], dev)
+            ops.prior_embed(ar, pc, buf)
+            taps.append((buf, wp, pc.shape[1] // 32))
+        h = ops.prior_packed_empty(M_, 1024, dev)
+        ops.prior_gemm([ops.prior_job(taps, b0, out_packed=h)], M_, 1024, ops.PRIOR_PACK, True, b0)
+        out = torch.empty(M_, 256, device=dev)
+        ops.prior_gemm([ops.prior_job([(h, W1p, 32)], b1, out_rows=out)], M_, 256, ops.PRIOR_ROWS, True, b0)
+        return out
+
+    a, b = old(), new()
+    ref = torch.relu(torch.relu(x.to(torch.bfloat16).float() @ W0.to(torch.bfloat16).float().t() + b0).to(torch.bfloat16).float()
+                     @ W1.to(torch.bfloat16).float().t() + b1)
+    print(f"heads: old vs fp32-of-bf16 reference {(a - ref).abs().max().item():.3e}, new {(b - ref).abs().max().item():.3e}, "
+          f"scale {ref.abs().max().item():.3f}", flush=True)
+    print(f"heads old: {timeit(old):.4f} ms   new (7 embeds + 2 products): {timeit(new):.4f} ms", flush=True)
+
+
 def prior():
     from network.gen_net import GenNet
     from dvq_hip import rng
