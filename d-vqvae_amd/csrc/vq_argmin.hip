@@ -619,9 +619,9 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_rot_kernel(
 // One wave owns 32 latents; z fragments are re-read (L1/L2) for every code tile and the
 // codebook tile is staged through LDS in chunks of CH dims.  Slower; used for the shapes
 // the register path does not cover (e.g. the 1024-wide object codebook).
-// SPLIT: the code tiles are spread over gridDim.y workgroups (few latents, long rows: more waves than n/32);
-// every workgroup folds its winner into idx_out with a 64-bit atomic min on (order-preserving distance bits,
-// code), and vq_unpack_key_kernel strips the distance afterwards.  idx_out must have been filled with 0xFF bytes.
+// Winners found by several waves for one latent (vq_argmin_few_kernel: the code tiles are shared out) meet in idx_out
+// through a 64-bit atomic min on (order-preserving distance bits, code); vq_unpack_key_kernel strips the distance
+// afterwards.  idx_out must have been filled with 0xFF bytes.
 __device__ __forceinline__ unsigned long long vq_pack_key(float d, int code) {
     const unsigned b = __builtin_bit_cast(unsigned, d);
     const unsigned ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -632,7 +632,7 @@ __global__ void vq_unpack_key_kernel(int64_t* __restrict__ idx, int64_t n) {
     if (i < n) idx[i] = idx[i] & 0xFFFFFFFFll;
 }
 
-template <int DT, int WAVES, bool SPLIT = false>
+template <int DT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void vq_argmin_generic_kernel(
     const typename VqTraits<DT>::elem* __restrict__ z, const char* __restrict__ packed,
     const float* __restrict__ e2, int64_t n, int D, int n_tiles, int64_t* __restrict__ idx_out) {
@@ -659,8 +659,7 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_generic_kernel(
         }
         const float z2 = part + __shfl_xor(part, 32, 64);
         Best best; best.d = __builtin_inff(); best.k = 0;
-        const int t_begin = SPLIT ? (int)blockIdx.y : 0, t_step = SPLIT ? (int)gridDim.y : 1;
-        for (int t = t_begin; t < n_tiles; t += t_step) {
+        for (int t = 0; t < n_tiles; ++t) {
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -719,11 +718,92 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_generic_kernel(
         }
         merge_halves(best);
         if (h == 0 && live) {
-            int64_t* dst = idx_out + grp * (WAVES * 32) + wave * 32 + r;
-            if (SPLIT) atomicMin(reinterpret_cast<unsigned long long*>(dst), vq_pack_key(best.d, best.k));
-            else *dst = (int64_t)best.k;
+            idx_out[grp * (WAVES * 32) + wave * 32 + r] = (int64_t)best.k;
         }
     }
+}
+
+// Few latents (the object codebook is searched with one 1024-d row per object): one wave per (32 latents, share of the
+// code tiles), no LDS and no barrier -- the packed codebook units and the latent fragments both go straight from
+// global memory into MFMA operands, PF units requested ahead of the products that use them.  |z|^2 comes from the
+// same fragments (fp32: the lane's half row in ascending order, the very fmaf chain of the generic kernel; bf16: its
+// own pass, the fragments interleave the two halves).  Winners of the tile shares meet in idx_out through vq_pack_key
+// (idx_out filled with 0xFF bytes, vq_unpack_key_kernel afterwards).
+template <int DT>
+__global__ __launch_bounds__(64) void vq_argmin_few_kernel(
+    const typename VqTraits<DT>::elem* __restrict__ z, const char* __restrict__ packed,
+    const float* __restrict__ e2, int64_t n, int D, int n_tiles, int64_t* __restrict__ idx_out) {
+    constexpr int DPU = VqTraits<DT>::kDimsPerUnit;
+    constexpr int PF = 8;
+    const int U = D / DPU;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    int64_t row = (int64_t)blockIdx.x * 32 + r;
+    const bool live = row < n;
+    if (!live) row = n - 1;
+    const typename VqTraits<DT>::elem* zr = z + row * D;
+    float part = 0.f;
+    if (DT == DVQ_BF16) {
+        for (int d = h * (D / 2); d < (h + 1) * (D / 2); d += 8) {
+            const u16x8 v = *reinterpret_cast<const u16x8*>(reinterpret_cast<const unsigned short*>(zr) + d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float x = bf16_bits_to_f32(v[j]); part = __builtin_fmaf(x, x, part); }
+        }
+    }
+    Best best; best.d = __builtin_inff(); best.k = 0;
+    bool first = true;
+    float z2 = 0.f;
+    for (int t = blockIdx.y; t < n_tiles; t += gridDim.y) {
+        const char* eu = packed + (int64_t)t * U * 1024 + lane * 16;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        u32x4 a[PF], b[PF], an[PF], bn[PF];
+        auto fetch = [&](int s0, u32x4 (&aa)[PF], u32x4 (&bb)[PF]) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int sj = (s0 + j < U) ? s0 + j : U - 1;
+                aa[j] = *reinterpret_cast<const u32x4*>(eu + (int64_t)sj * 1024);
+                if (DT == DVQ_BF16) bb[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(zr) + vq_dim_bf16(sj, h, 0));
+                else bb[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(zr) + vq_dim_f32(sj, h, 0, D));
+            }
+        };
+        fetch(0, a, b);
+        for (int s0 = 0; s0 < U; s0 += PF) {
+            if (s0 + PF < U) fetch(s0 + PF, an, bn);
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                if (s0 + j < U) {
+                    if constexpr (DT == DVQ_BF16) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]), acc, 0, 0, 0);
+                    } else {
+                        const f32x4 af = __builtin_bit_cast(f32x4, a[j]), bf = __builtin_bit_cast(f32x4, b[j]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc, 0, 0, 0);
+                            if (first) part = __builtin_fmaf(bf[i], bf[i], part);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PF; ++j) { a[j] = an[j]; b[j] = bn[j]; }
+        }
+        if (first) { z2 = part + __shfl_xor(part, 32, 64); first = false; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 e = *reinterpret_cast<const f32x4*>(e2 + t * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float t1 = z2 + e[q];
+                const float d = __builtin_fmaf(-2.0f, acc[4 * g + q], t1);
+                const int code = t * 32 + 8 * g + 4 * h + q;
+                if (d < best.d) { best.d = d; best.k = code; }
+            }
+        }
+    }
+    merge_halves(best);
+    if (h == 0 && live) atomicMin(reinterpret_cast<unsigned long long*>(idx_out + (int64_t)blockIdx.x * 32 + r), vq_pack_key(best.d, best.k));
 }
 
 // ------------------------------------- wide rows (D a multiple of 256 / 128), many latents
@@ -1006,11 +1086,11 @@ static int launch_search(const void* z, const char* ws, const VqPlan& p, int64_t
         if (split > 1) {
             if (hipMemsetAsync(idx_out, 0xFF, (size_t)n * sizeof(int64_t), st) != hipSuccess)
                 return fail(DVQ_ELAUNCH, "vq_argmin: cannot initialise the index buffer");
-            hipLaunchKernelGGL((vq_argmin_generic_kernel<DT, 1, true>), dim3((unsigned)groups, (unsigned)split), dim3(64), 0, st,
+            hipLaunchKernelGGL((vq_argmin_few_kernel<DT>), dim3((unsigned)groups, (unsigned)split), dim3(64), 0, st,
                                reinterpret_cast<const typename VqTraits<DT>::elem*>(z), ws, reinterpret_cast<const float*>(ws + p.e2_off),
                                n, D, p.n_tiles, idx_out);
             hipLaunchKernelGGL(vq_unpack_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx_out, n);
-            return check_launch("vq_argmin(generic, split)");
+            return check_launch("vq_argmin(few latents)");
         }
         hipLaunchKernelGGL((vq_argmin_generic_kernel<DT, 1>), dim3((unsigned)groups), dim3(64), 0, st,
                            reinterpret_cast<const typename VqTraits<DT>::elem*>(z), ws, reinterpret_cast<const float*>(ws + p.e2_off),
