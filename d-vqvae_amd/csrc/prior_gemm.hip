@@ -715,9 +715,34 @@ __global__ __launch_bounds__(256) void prior_sample_kernel(const float* __restri
     }
 }
 
+// u[i][c] in [0,1): splitmix64 of the counter (first_id + i) * 1024 + c + seed * golden ratio, mixed twice; the top 53
+// bits.  The draw of an object's cell is a pure function of (seed, global object id, cell), whatever the batch or rank.
+__device__ __forceinline__ unsigned long long pg_splitmix(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void prior_uniforms_kernel(long long first_id, long long n, int n_cells, unsigned long long offset, double* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_cells) return;
+    const unsigned long long ctr = (unsigned long long)(first_id + t / n_cells) * 1024ull + (unsigned long long)(t % n_cells) + offset;
+    const unsigned long long bits = pg_splitmix(pg_splitmix(ctr) + 0x632BE59BD9B4E019ull);
+    out[t] = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+}
+
 }  // namespace dvq
 
 using namespace dvq;
+
+extern "C" int dvq_prior_uniforms(int64_t first_id, int64_t n, int n_cells, uint64_t seed, double* out, void* stream) {
+    if (n < 0 || n_cells < 1 || n_cells > 1024 || (n > 0 && !out)) return fail(DVQ_EINVAL, "prior_uniforms: n >= 0, 1..1024 cells, an output buffer");
+    if (n == 0) return DVQ_OK;
+    const unsigned long long offset = (unsigned long long)seed * 0x9E3779B97F4A7C15ull;
+    const long long total = (long long)n * n_cells;
+    hipLaunchKernelGGL(prior_uniforms_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), (long long)first_id,
+                       (long long)n, n_cells, offset, out);
+    return check_launch("prior_uniforms");
+}
 
 static bool pg_dtype_ok(int dtype) { return dtype == DVQ_BF16 || dtype == DVQ_F32; }
 

@@ -87,6 +87,7 @@ SIGNATURES = {
     "dvq_prior_embed": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvq_prior_gemm": (c_int, [POINTER(DvqPriorJob), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dvq_prior_gather_rows": (c_int, [POINTER(DvqPriorGather), c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dvq_prior_uniforms": (c_int, [c_int64, c_int64, c_int, ctypes.c_uint64, c_void_p, c_void_p]),
     "dvq_prior_vrow": (c_int, [POINTER(DvqPriorVRow), c_int, c_int, c_void_p]),
     "dvq_prior_sample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,

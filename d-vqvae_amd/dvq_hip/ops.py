@@ -468,6 +468,17 @@ def prior_sample(logits: torch.Tensor, u: torch.Tensor, x_out: torch.Tensor, tab
     _lib.check(rc, "dvq_prior_sample")
 
 
+def prior_uniforms(first_id: int, n: int, n_cells: int, seed: int, device) -> torch.Tensor:
+    """float64 [n, n_cells] uniforms of objects first_id .. first_id + n - 1: the values of dvq_hip.rng.uniforms, one launch."""
+    out = torch.empty(n, n_cells, dtype=torch.float64, device=device)
+    if n > 0:
+        with torch.cuda.device(device):
+            rc = _lib.load().dvq_prior_uniforms(int(first_id), n, n_cells, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out),
+                                                torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(rc, "dvq_prior_uniforms")
+    return out
+
+
 def prior_gather_rows(pairs, idx: torch.Tensor, M: int, V: int, dtype_code: int = DVQ_BF16) -> None:
     """out[m] <- table[idx[m]] for every (table, out, features) of `pairs`: packed activations of V rows handed out to
     the M rows of a batch.  One launch per 96 buffers."""
@@ -514,6 +525,19 @@ def prior_vrow(rows, k_blocks: int, bias, cond, label, out_packed, out_pre, M: i
 # first product), the first layer's output stays packed in bf16 (exactly the rounding the second layer's operand
 # load would apply) and the second layer writes fp32 rows.  Same LDS-staged kernel as the prior's products: 2-3x
 # the rate of the register-operand dvq_linear_bf16 at these shapes.
+_ROW_IDS = {}
+
+
+def _row_ids(M: int, device) -> torch.Tensor:
+    """0 .. M-1 on `device`, made once per size."""
+    key = (M, str(device))
+    if key not in _ROW_IDS:
+        if len(_ROW_IDS) > 16:
+            _ROW_IDS.clear()
+        _ROW_IDS[key] = torch.arange(M, dtype=torch.int64, device=device)
+    return _ROW_IDS[key]
+
+
 def head_pack(W0: torch.Tensor, widths, W1: torch.Tensor):
     """Packed bf16 weights for head_mlp_bf16: W0 [N0, sum(widths)] cut into one block per input piece, W1 [N1, N0]."""
     offs = [0]
@@ -549,7 +573,7 @@ def head_mlp_bf16(pieces, packed, b0: torch.Tensor, b1: torch.Tensor, relu1: boo
             if pc.shape != (M, d) or pc.dtype != torch.float32 or not pc.is_contiguous():
                 raise RuntimeError("head_mlp_bf16: pieces must be contiguous float32 [M, d]")
             if ar is None:
-                ar = torch.arange(M, dtype=torch.int64, device=dev)
+                ar = _row_ids(M, dev)
             prior_embed(ar, pc, buf, DVQ_BF16)
         taps.append((buf, wp, d // 32))
     h = prior_packed_empty(M, N0, dev, False, DVQ_BF16)

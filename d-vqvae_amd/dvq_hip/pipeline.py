@@ -9,7 +9,7 @@ from typing import Optional
 
 import torch
 
-from . import parallel, rng, set_compute_dtype, synth
+from . import ops, parallel, rng, set_compute_dtype, synth
 from .mano_io import Struct
 
 
@@ -72,8 +72,10 @@ class GraspGenerator:
             param = torch.zeros((0, 61), dtype=torch.float32, device=obj.device)
             verts = torch.zeros((0, 778, 3), dtype=torch.float32, device=obj.device)
         elif x_tilde is None:
-            ids = torch.arange(first_id, first_id + B, device=obj.device)
-            u = rng.uniforms(ids, 9, self.seed)
+            if obj.is_cuda:
+                u = ops.prior_uniforms(first_id, B, 9, self.seed, obj.device)      # = rng.uniforms of these ids
+            else:
+                u = rng.uniforms(torch.arange(first_id, first_id + B, device=obj.device), 9, self.seed)
             recon, pos = self.model.gen(obj, uniforms=u)
         else:
             recon, pos = self.model.gen(obj, x_tilde=x_tilde)

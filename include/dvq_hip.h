@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 109   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 110   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -320,6 +320,12 @@ int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream);
  * of `emb_dtype` (the next cell's input).  logits: fp32 [M, n_classes], n_classes <= 1024. */
 int dvq_prior_sample(const float* logits, int n_classes, int M, const double* u, int64_t u_stride, int64_t* x_out,
                      int64_t x_stride, const float* table, int d, int emb_dtype, void* emb_out, void* stream);
+
+/* The uniforms dvq_prior_sample consumes, out[i*n_cells + c] in [0,1) for object first_id + i and grid cell c: the top 53
+ * bits of splitmix64 applied twice to the counter (first_id + i)*1024 + c + seed*0x9E3779B97F4A7C15 (with
+ * 0x632BE59BD9B4E019 added between the two rounds).  No counterpart in the reference (which draws from torch's global
+ * generator, models.py:193); a pure function of (seed, object id, cell), so any sharding of a batch draws the same grids. */
+int dvq_prior_uniforms(int64_t first_id, int64_t n, int n_cells, uint64_t seed, double* out, void* stream);
 
 #ifdef __cplusplus
 }

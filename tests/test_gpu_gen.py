@@ -161,6 +161,17 @@ def test_prior_rows_by_class_equal_rows_evaluated_one_by_one(dtype):
     assert torch.equal(got, want)
 
 
+def test_uniforms_kernel_equals_the_tensor_formulation():
+    """dvq_prior_uniforms against dvq_hip.rng.uniforms (splitmix64 in wrapping int64 tensor arithmetic, also the CPU
+    path): bit-equal for ids beyond 2^32, a negative-wrapping seed offset and a ragged count."""
+    from dvq_hip import rng
+    for first, n, seed in ((0, 4096, 0), (123456789012, 77, 12345), (5, 1, 2 ** 40 + 3)):
+        want = rng.uniforms(torch.arange(first, first + n, device=DEV), 9, seed)
+        got = ops.prior_uniforms(first, n, 9, seed, torch.device(DEV))
+        assert torch.equal(got, want) and float(got.min()) >= 0.0 and float(got.max()) < 1.0
+        assert torch.equal(rng.uniforms(torch.arange(first, first + n), 9, seed), want.cpu())
+
+
 def test_prior_vrow_kernel_equals_three_per_cell_products():
     """The fused row kernel against three dvq_prior_gemm jobs on the same operands: same taps, another summation
     order, so the packed bf16 results may differ by an ulp of bf16 (2^-8 relative) and no more."""
