@@ -46,11 +46,10 @@ class GenNet(nn.Module):
 
     def _decode(self, part_idx, obj_feat_type, obj_feat_pos):
         """codebook rows + object feature -> decoder -> MANO -> recon encoder -> pos decoder
-        (gen_net.py:101-123).  part_idx: int64 [B,6]."""
+        (gen_net.py:101-123).  part_idx: six int64 [B] index vectors (may be strided views)."""
         B = obj_feat_type.shape[0]
         # six codebook rows and the un-quantised object feature (gen_net.py:109), handed to the decoder piece by piece
-        pieces = [(part_idx[:, k].contiguous(), getattr(self, f"vqvae{k}").vector_quantization.embedding.weight.detach())
-                  for k in range(6)]
+        pieces = [(part_idx[k], getattr(self, f"vqvae{k}").vector_quantization.embedding.weight.detach()) for k in range(6)]
         recon = self.decoder.forward_pieces(pieces + [obj_feat_type]).view(B, 55)
         zero3 = torch.zeros(B, 3, dtype=torch.float32, device=recon.device)
         verts = self.rh_mano(betas=recon[:, :10], global_orient=zero3, hand_pose=recon[:, 10:55].contiguous(),
@@ -80,7 +79,8 @@ class GenNet(nn.Module):
             label = idx6[:, 0]
             x_tilde = self.GatedPixelCNN.generate(None, label, shape=(3, 3), batch_size=B, generator=generator,
                                                   uniforms=uniforms)
-        part_idx = torch.stack([x_tilde[:, r, c] for r, c in PART_CELLS], dim=1).to(torch.int64)
+        xt = x_tilde.to(torch.int64)
+        part_idx = [xt[:, r, c] for r, c in PART_CELLS]      # strided views of the grid: no gather, no copies
         self.last_x_tilde = x_tilde
         self.last_idx6 = idx6
         return self._decode(part_idx, obj_feat_type, obj_feat_pos)
