@@ -302,9 +302,11 @@ class GatedPixelCNN(nn.Module):
                                           out_pre=HV[l][j]))
             self._gemm(jobs, M, 2 * d, ops.PRIOR_GATE)
 
-    def _horizontal_cell(self, bufs, i, j, M, label):
+    def _horizontal_cell(self, bufs, i, j, M, label, cond_with_v2h=None):
         """Horizontal stack and output head of cell (i, j): two launches per layer (taps + projected vertical
-        features + gate; residual 1x1), two for the head; leaves the cell's logits in bufs["logits"]."""
+        features + gate; residual 1x1), two for the head; leaves the cell's logits in bufs["logits"].
+        cond_with_v2h: per layer a [classes, 2d] table that already holds class embedding + projected vertical
+        features (grid row 0, where the vertical features depend on the class alone): the projection tap is dropped."""
         layers, (wo1, bo1, wo2, bo2) = self._packed
         XV, HV, XHb, OUT, HID, logits = (bufs[k] for k in ("XV", "HV", "XH", "OUT", "HID", "logits"))
         L, d = len(layers), self.dim
@@ -322,8 +324,10 @@ class GatedPixelCNN(nn.Module):
                     taps.append((XH[l], w, kb))
                 elif c == j - 1:
                     taps.append((XHp[l], w, kb))
-            taps.append((HV[l][j], t.v2h, 2 * kb))
-            self._gemm([ops.prior_job(taps, t.horiz_bias, cond=t.cond, label=label, out_packed=OUT)], M, 2 * d, ops.PRIOR_GATE)
+            if cond_with_v2h is None:
+                taps.append((HV[l][j], t.v2h, 2 * kb))
+            self._gemm([ops.prior_job(taps, t.horiz_bias, cond=t.cond if cond_with_v2h is None else cond_with_v2h[l], label=label,
+                                      out_packed=OUT)], M, 2 * d, ops.PRIOR_GATE)
             self._gemm([ops.prior_job([(OUT, t.resid, kb)], t.resid_bias, resid=XH[l] if t.residual else None,
                                       out_packed=XH[l + 1])], M, d, ops.PRIOR_PACK)
         self._gemm([ops.prior_job([(XH[L], wo1, kb)], bo1, out_packed=HID)], M, bo1.numel(), ops.PRIOR_PACK, True)
@@ -333,7 +337,9 @@ class GatedPixelCNN(nn.Module):
     # grid row 0 (nothing above it) and the whole of cell (0, 0) (nothing left of it), logits included.  Like the
     # packed weights they are constants of the checkpoint: evaluated for ONE row per class with the same kernels when
     # the weights are first used (_class_rows) and handed out to the rows of a batch by their label
-    # (_first_row_by_class) -- bit-equal to evaluating every row.
+    # (_first_row_by_class) -- bit-equal to evaluating every row.  The rest of grid row 0 reads the row's vertical
+    # features only through their 1x1 projection into the gate: that projection, per class as well, is added to the
+    # class-embedding table those cells' gate epilogue looks up, so the tap and the copies of the features go.
     def _by_class(self, B):
         return self.class_rows and B >= self.class_rows_min_rows
 
@@ -350,6 +356,19 @@ class GatedPixelCNN(nn.Module):
             cls["label"].copy_(torch.arange(V, dtype=torch.int64, device=dev))
             self._vertical_row(cls, 0, V, shape, cls["label"], use_vrow)
             self._horizontal_cell(cls, 0, 0, V, cls["label"])
+            # cells (0, 1..): their projected vertical features are per class too -- folded, with the class embedding,
+            # into the table the gate epilogue looks up by label (one tap less in those cells' gate products)
+            layers = self._packed[0]
+            d = self.dim
+            zero = torch.zeros(2 * d, dtype=torch.float32, device=dev)
+            cls["cond_v2h"] = {}
+            for j in range(1, shape[1]):
+                tabs = []
+                for l, t in enumerate(layers):
+                    proj = torch.empty(V, 2 * d, dtype=torch.float32, device=dev)
+                    self._gemm([ops.prior_job([(cls["HV"][l][j], t.v2h, 2 * d // 32)], zero, out_rows=proj)], V, 2 * d, ops.PRIOR_ROWS)
+                    tabs.append((t.cond + proj).contiguous())
+                cls["cond_v2h"][j] = tabs
             self._cls[key] = cls
         return self._cls[key]
 
@@ -360,7 +379,6 @@ class GatedPixelCNN(nn.Module):
         cls = self._class_rows(shape, use_vrow)
         V = cls["label"].shape[0]
         pairs = [(cls["XV"][l][0][j], bufs["XV"][l][0][j], d) for l in range(1, L) for j in range(W)]       # read by row 1
-        pairs += [(cls["HV"][l][j], bufs["HV"][l][j], 2 * d) for l in range(L) for j in range(1, W)]         # cells (0, 1..)
         pairs += [(cls["XH"][0][l], bufs["XH"][0][l], d) for l in range(1, L)]                              # cell (0, 1)
         ops.prior_gather_rows(pairs, label, B, V, self._packed_key[1])
         ops.vq_gather(label, cls["logits"], out=bufs["logits"])
@@ -385,7 +403,8 @@ class GatedPixelCNN(nn.Module):
                 self._vertical_row(bufs, i, B, shape, label, use_vrow)
             for j in range(W):
                 if not (i == 0 and j == 0 and by_class):
-                    self._horizontal_cell(bufs, i, j, B, label)
+                    table = self._class_rows(shape, use_vrow)["cond_v2h"][j] if (i == 0 and by_class) else None
+                    self._horizontal_cell(bufs, i, j, B, label, table)
                 if uniforms is not None and not return_probs:
                     # softmax, draw, grid write and embedding of the drawn code in one launch
                     ops.prior_sample(logits, uniforms[:, i * W + j], x[:, i, j], emb, XV[0][i][j], code)

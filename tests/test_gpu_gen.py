@@ -130,12 +130,15 @@ def test_prior_bf16_kernels_vs_fp32():
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_prior_rows_by_class_equal_rows_evaluated_one_by_one(dtype):
     """Grid row 0's vertical stack and cell (0, 0) see nothing but the class label; generate() evaluates them once per
-    class and hands the rows out (dvq_prior_gather_rows).  Same kernels, same numbers: the sampled grids and the
-    per-cell distributions must be bit-equal to evaluating every row, at a ragged batch and at one grid."""
+    class and hands the rows out (dvq_prior_gather_rows).  Same kernels, same numbers: cell (0, 0)'s distribution is
+    bit-equal to evaluating every row.  In cells (0, 1..) the projected vertical features reach the gate through the
+    per-class table instead of the accumulator (another fp32 summation order): the distributions agree to rounding
+    wherever the grids drawn so far agree, and nearly all grids agree.  At a ragged batch and at one grid."""
     from dvq_hip import ops, rng
     model, _ = build()
     prior = model.GatedPixelCNN
     prior.compute_dtype = dtype
+    tol = 1e-5 if dtype == torch.float32 else 5e-3
     for B in (301, 1):
         lab = torch.randint(0, 128, (B,), device=DEV, generator=torch.Generator(DEV).manual_seed(4))
         u = rng.uniforms(torch.arange(B, device=DEV), 9, seed=11)
@@ -144,10 +147,16 @@ def test_prior_rows_by_class_equal_rows_evaluated_one_by_one(dtype):
             prior.class_rows = on
             out[on] = prior.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u, return_probs=True)
         prior.class_rows = True
+        (xa, pa), (xb, pb) = out[True], out[False]
         if B > 32:                               # (one grid takes the k-split kernel: another summation order)
-            assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
-        else:
-            assert (out[True][1] - out[False][1]).abs().max().item() <= (1e-5 if dtype == torch.float32 else 5e-3)
+            assert torch.equal(pa[:, 0], pb[:, 0])
+        same = torch.ones(B, dtype=torch.bool, device=DEV)       # grids equal in every cell drawn before this one
+        for c in range(9):
+            if bool(same.any()):
+                assert (pa[same, c] - pb[same, c]).abs().max().item() <= tol, c
+            same &= xa.reshape(B, 9)[:, c] == xb.reshape(B, 9)[:, c]
+        # (bf16: a product rounded the other way moves a draw that sat on a boundary, a few grids in a thousand)
+        assert same.float().mean().item() >= (1.0 if B == 1 else 0.99 if dtype == torch.float32 else 0.97)
     # the gather itself: packed rows of a table handed out by index, against prior_embed of the same rows
     code = ops.DVQ_BF16 if dtype == torch.bfloat16 else ops.DVQ_F32
     V, M, d = 50, 77, 96
