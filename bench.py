@@ -131,7 +131,7 @@ def vq_microbench(device, n_rows=1 << 20, iters=5):
 def prior_roofline(gen, B, device, iters=20):
     """The prior's dominant launch -- the horizontal-stack gate product of one layer and cell (bf16: [B,2048] x
     [2048,1024] over three taps) -- launched alone with HIP events around it.  It is bound by operand delivery from L2
-    into LDS: every 128-row x 64-column workgroup tile pulls its own weight and activation units."""
+    into LDS: every workgroup tile (128 rows x 128 or 64 columns) pulls its own weight and activation units."""
     pr = gen.model.GatedPixelCNN
     if pr.compute_dtype != torch.bfloat16 or B < 256:
         return None
@@ -155,6 +155,8 @@ def prior_roofline(gen, B, device, iters=20):
     M, N, K = B, 2 * d, 4 * d
     gy = (M + 127) // 128                                  # row tiles of 128 samples
     no = 4 if (N // 128) * gy >= 512 else 2                # column tile of 128 or 64 features (dvq_prior_gemm's rule)
+    if no == 2 and (N // 128) * gy >= 256:                 # ... 64-wide tiles pair up in one eight-wave workgroup
+        no = 4
     gx = N // (32 * no)
     l2_bytes = 2.0 * K * (gy * N + gx * M)                 # every row tile reads the weights, every column tile the activations
     flops = 2.0 * M * N * K
@@ -164,8 +166,9 @@ def prior_roofline(gen, B, device, iters=20):
             "traffic": None, "avg_launch_ms": round(ms, 5), "launches_timed": iters, "l2_to_lds_bytes_per_launch": l2_bytes,
             "tflops": round(flops / ms / 1e9, 1), "frac_mfma_peak": round(flops / ms / 1e9 / PEAK_TFLOPS["bf16"], 4),
             "note": "launched back to back outside the replayed graph (independent launches: no dependent-chain stalls); "
-                    "120 such launches + 120 residual 1x1 products + 30 vertical-row launches make one grid batch "
-                    "(grid row 0's vertical stack and cell (0,0) are per-class constants of the weights)"}
+                    "120 such launches (30 of them, in grid row 0, with one tap less) + 120 residual 1x1 products + 30 "
+                    "vertical-row launches make one grid batch (grid row 0's vertical stack and cell (0,0) are "
+                    "per-class constants of the weights)"}
 
 
 def cpu_baseline(with_prior, reps=10, batch=16):

@@ -21,8 +21,8 @@
 //         optionally also y without the class term     -> packed bf16 (N features)
 //   ROWS  y = acc + bias (relu)                        -> fp32 [M, N] row-major (logits; heads)
 //
-// Tiling: a workgroup of four waves owns NO (4 or 2) output-feature tiles x 4 sample tiles; each
-// wave multiplies all NO weight tiles (shared through LDS) with its own sample tile.
+// Tiling: a workgroup owns 4 sample tiles x 2..4 output-feature tiles; a wave multiplies NO weight
+// tiles (shared through LDS) with one sample tile (four waves, or eight in two feature groups).
 #include "common.h"
 
 namespace dvq {
@@ -252,62 +252,64 @@ __global__ __launch_bounds__(kPgSmallWaves * 64) void prior_gemm_small_kernel(Pg
     pg_epilogue<DT, EPI, NO>(job, acc, ob, 0, lane, M, N, 1, relu);
 }
 
-// grid: x = output-feature group (NO tiles of 32; for GATE NO/2 + the matching NO/2 of the upper
-//       half), y = group of 4 sample tiles (one per wave), z = job.  One workgroup per CU.
+// grid: x = output-feature group (FG x NO tiles of 32; for GATE half of them + the matching half of the upper
+//       half), y = group of 4 sample tiles, z = job.  4 x FG waves: wave (ws, wf) owns sample tile ws and the NO
+//       tiles of feature group wf.
 //
 // Pipeline: every operand byte reaches LDS by direct global->LDS loads (no register-destination
-// load inside the loop), in stages of KS k-blocks (weights NO x KS x 2 KiB shared by the four waves,
-// activations KS x 2 KiB per wave) through a ring of R stage buffers.  A wave waits only for ITS
+// load inside the loop), in stages of KS k-blocks (weights FG x NO x KS x 2 KiB, activations 4 x KS x 2 KiB,
+// dealt to the waves unit by unit) through a ring of R stage buffers.  A wave waits only for ITS
 // loads of the stage it is about to read with a counted s_waitcnt vmcnt (the younger stages stay
 // in flight), then one s_barrier makes every wave's part visible and frees the buffer read R-1
 // stages ago, which is immediately refilled.
-// A 128 x 128 output tile per workgroup is all a [4096 x 1024] product leaves for each of the 256
-// CUs (64 FLOP per byte moved from L2); 64-wide tiles, two workgroups per CU, move 1.5x the bytes and
-// are still faster: no unit is saturated (matrix pipe 17 %, L2 request rate 25 % of its peak, waves
-// waiting 41 % of their time by the counters) -- the loop is bound by the latency of a stage's
-// barrier and load wait, which a second workgroup hides and a deeper ring does not (R = 4, 5: +-1 %).
+// A 128 x 128 output tile per CU is all a [4096 x 1024] product leaves for each of the 256
+// CUs (64 FLOP per byte moved from L2).  No unit is saturated (matrix pipe 17 %, L2 request rate 25 % of its
+// peak, waves waiting 41 % of their time by the counters): the loop is bound by the latency of a stage's
+// barrier and load wait, which a second wave per SIMD hides and a deeper ring does not (R = 4, 5: +-1 %).
+// Four waves with 128 features each (one wave per SIMD) are slower than two four-wave workgroups of 64
+// features per CU although those move 1.5x the bytes; eight waves of 64 features in ONE workgroup (FG = 2)
+// keep two waves per SIMD and share the activations: 6.86 -> 6.63 ms per 4096 grids.
 // bf16 stages hold two k-blocks (half as many barriers per product: 7.19 -> 6.92 ms per 4096 grids),
 // fp32 stages one (the same bytes).
-template <int DT, int EPI, int NO, int KS>
-__global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
+template <int DT, int EPI, int NO, int KS, int FG>
+__global__ __launch_bounds__(4 * FG * 64) void prior_gemm_kernel(PgJobs jobs, int M, int N, int relu) {
     // These products form a long dependent chain of short launches; when another stream's long-running kernel
     // (the point-cloud encoder) shares the CU, win the SIMD's issue arbitration so the chain keeps its pace.
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PgJobDev& job = jobs.j[blockIdx.z];
-    constexpr int NS = 1;
+    constexpr int WV = 4 * FG;                                   // waves: 4 sample tiles x FG feature groups
     constexpr int UPB = PgT<DT>::UPB;
     constexpr int KU = KS * UPB;                                 // units per operand tile and stage
-    constexpr int W_UNITS = NO * KU;
-    constexpr int X_UNITS = kPgWaves * KU;
+    constexpr int W_UNITS = FG * NO * KU;
+    constexpr int X_UNITS = 4 * KU;
     constexpr int STAGE_BYTES = (W_UNITS + X_UNITS) * 1024;
     constexpr int R = kPgRing;
-    constexpr int GLDS_PER_STAGE = W_UNITS / kPgWaves + KU;      // per wave
+    static_assert(W_UNITS % WV == 0 && X_UNITS % WV == 0, "a stage's units are dealt evenly to the waves");
+    constexpr int GLDS_PER_STAGE = (W_UNITS + X_UNITS) / WV;     // per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
+    const int ws = wave & 3, wf = wave >> 2;                     // this wave's sample tile and feature group
     const int SB = (M + 31) / 32;
     const int n_ob = N / 32;
 
     // column tile bx (weights shared along it), row tile by (activations shared along it), dealt XCD-aware
     int bx, by;
     xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    // output-feature block of tile t of feature group g (GATE: the first half of a group's tiles are tanh blocks,
+    // the second half their sigmoid partners in the upper half of the features)
+    auto block_of = [&](int g, int t) {
+        if (EPI == PG_GATE) return (t < NO / 2 ? 0 : n_ob / 2) + (FG * NO / 2) * bx + g * (NO / 2) + t % (NO / 2);
+        return FG * NO * bx + g * NO + t;
+    };
     int ob[NO];
-    if (EPI == PG_GATE) {
-        const int half = n_ob / 2;
 #pragma unroll
-        for (int t = 0; t < NO / 2; ++t) { ob[t] = (NO / 2) * bx + t; ob[t + NO / 2] = half + (NO / 2) * bx + t; }
-    } else {
-#pragma unroll
-        for (int t = 0; t < NO; ++t) ob[t] = NO * bx + t;
-    }
-    int sb[NS];
-    sb[0] = by * kPgWaves + wave;
-    const bool live0 = sb[0] < SB;
-    const bool live1 = false;
-    if (sb[0] >= SB) sb[0] = SB - 1;   // a surplus tile recomputes the last one; its stores are skipped
+    for (int t = 0; t < NO; ++t) ob[t] = block_of(wf, t);
+    int sbw = by * 4 + ws;
+    const bool live = sbw < SB;
+    if (!live) sbw = SB - 1;           // a surplus tile recomputes the last one; its stores are skipped
 
-    f32x16 acc[NO][NS];
+    f32x16 acc[NO][1];
 #pragma unroll
     for (int t = 0; t < NO; ++t)
 #pragma unroll
@@ -316,22 +318,27 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
     int total_stages = 0;
     for (int t = 0; t < job.n_taps; ++t) total_stages += job.taps[t].kb / KS;
 
-    // one stage: W units [t][k][s2] then X units [wave][k][s2]
+    // one stage: W units [group][t][k][s2] then X units [sample tile][k][s2], dealt to the waves unit by unit
     auto issue = [&](int tap, int kb0, int buf) {
         const char* w = job.taps[tap].w;
         const char* x = job.taps[tap].x;
         const int KB = job.taps[tap].kb;
         char* dst = smem + buf * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < W_UNITS / kPgWaves; ++i) {
-            const int u = wave + kPgWaves * i;
-            const int t = u / KU, q = u % KU;
-            pg_glds16(w + ((int64_t)(ob[t] * KB + kb0) * UPB + q) * 1024 + lane * 16, dst + u * 1024);
+        for (int i = 0; i < W_UNITS / WV; ++i) {
+            const int u = wave + WV * i;
+            const int gt = u / KU, q = u % KU;
+            pg_glds16(w + ((int64_t)(block_of(gt / NO, gt % NO) * KB + kb0) * UPB + q) * 1024 + lane * 16, dst + u * 1024);
         }
 #pragma unroll
-        for (int q = 0; q < KU; ++q)
-            pg_glds16(x + (((int64_t)(kb0 + q / UPB) * SB + sb[0]) * UPB + (q % UPB)) * 1024 + lane * 16,
-                      dst + (W_UNITS + wave * KU + q) * 1024);
+        for (int i = 0; i < X_UNITS / WV; ++i) {
+            const int u = wave + WV * i;
+            const int tile = u / KU, q = u % KU;
+            int sbt = by * 4 + tile;
+            if (sbt >= SB) sbt = SB - 1;
+            pg_glds16(x + (((int64_t)(kb0 + q / UPB) * SB + sbt) * UPB + (q % UPB)) * 1024 + lane * 16,
+                      dst + (W_UNITS + u) * 1024);
+        }
     };
     auto advance = [&](int& tp, int& k0) {
         k0 += KS;
@@ -360,26 +367,26 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_gemm_kernel(PgJobs jobs, 
 #pragma unroll
         for (int q = 0; q < KU; ++q) {
             if constexpr (DT == DVQ_BF16) {
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sbuf + (W_UNITS + wave * KU + q) * 1024);
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sbuf + (W_UNITS + ws * KU + q) * 1024);
 #pragma unroll
                 for (int t = 0; t < NO; ++t) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sbuf + (t * KU + q) * 1024);
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t][0], 0, 0, 0);
+                    const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(sbuf + ((wf * NO + t) * KU + q) * 1024);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, xf, acc[t][0], 0, 0, 0);
                 }
             } else {
-                const f32x4 xf = *reinterpret_cast<const f32x4*>(sbuf + (W_UNITS + wave * KU + q) * 1024);
-                f32x4 wf[NO];
+                const f32x4 xf = *reinterpret_cast<const f32x4*>(sbuf + (W_UNITS + ws * KU + q) * 1024);
+                f32x4 wfr[NO];
 #pragma unroll
-                for (int t = 0; t < NO; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sbuf + (t * KU + q) * 1024);
+                for (int t = 0; t < NO; ++t) wfr[t] = *reinterpret_cast<const f32x4*>(sbuf + ((wf * NO + t) * KU + q) * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int t = 0; t < NO; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t][j], xf[j], acc[t][0], 0, 0, 0);
+                    for (int t = 0; t < NO; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[t][j], xf[j], acc[t][0], 0, 0, 0);
             }
         }
     }
 
-    if (live0) pg_epilogue<DT, EPI, NO>(job, acc, ob, sb[0], lane, M, N, SB, relu);
+    if (live) pg_epilogue<DT, EPI, NO>(job, acc, ob, sbw, lane, M, N, SB, relu);
 }
 
 // W [N, K] (fp32, element (n,k) at W[n*ldn + k*ldk]) -> packed A-fragment units
@@ -495,6 +502,7 @@ __global__ __launch_bounds__(256) void prior_gather_rows_kernel(PgGatherList lis
 // and each weight unit once per k-block instead of once per cell: 149 FLOP per byte moved from L2 against 64 for
 // the per-cell product above, which is what bounds it.  Stage = one input row x one k-block: 3 columns of
 // activations (2 units per wave each) + 3 taps of weights (NO x 2 units each), 48 KiB, ring of three.
+// (The same tile on eight waves -- two feature groups, 164 registers, two waves per SIMD -- runs at the same speed.)
 struct PvDesc {
     const char* x[2][3];
     const char* w[2][3];
@@ -894,21 +902,26 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
     // traffic per FLOP: 8.68 -> 8.55 ms per 4096 grids, 6.59 -> 6.20 ms per 2048
     const int64_t want = 2 * kNumCU;
     const int no = ((int64_t)(N / 128) * gy * n_jobs >= want || (N % 64) != 0 || (epilogue == PG_GATE && (N % 128) != 0)) ? 4 : 2;
-    const dim3 grid(N / (32 * no), gy, n_jobs);
-    const size_t lds = (size_t)kPgRing * (no * ks * upb + kPgWaves * ks * upb) * 1024;
-    const dim3 blk(kPgWaves * 64);
-#define DVQ_PG_LAUNCH3(D, E, NO_, KS_)                                                                   \
+    // 64-wide tiles in pairs: one eight-wave workgroup per CU where that still gives every CU one (the gate products)
+    const bool eight = no == 2 && dtype == DVQ_BF16 && (N % 128) == 0 && (epilogue != PG_GATE || (N % 256) == 0) &&
+                       (int64_t)(N / 128) * gy * n_jobs >= kNumCU;
+    const int fg = eight ? 2 : 1;
+    const dim3 grid(N / (32 * no * fg), gy, n_jobs);
+    const size_t lds = (size_t)kPgRing * (fg * no * ks * upb + 4 * ks * upb) * 1024;
+    const dim3 blk(4 * fg * 64);
+#define DVQ_PG_LAUNCH3(D, E, NO_, KS_, FG_)                                                                   \
     do {                                                                                                 \
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_gemm_kernel<D, E, NO_, KS_>), lds, "prior_gemm")) return rc; \
-        hipLaunchKernelGGL((prior_gemm_kernel<D, E, NO_, KS_>), grid, blk, lds, st, dev, M, N, relu);    \
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_gemm_kernel<D, E, NO_, KS_, FG_>), lds, "prior_gemm")) return rc; \
+        hipLaunchKernelGGL((prior_gemm_kernel<D, E, NO_, KS_, FG_>), grid, blk, lds, st, dev, M, N, relu);    \
     } while (0)
 #define DVQ_PG_LAUNCH(E)                                                   \
     do {                                                                   \
         if (dtype == DVQ_F32) {                                            \
-            if (no == 4) DVQ_PG_LAUNCH3(DVQ_F32, E, 4, 1);                 \
-            else DVQ_PG_LAUNCH3(DVQ_F32, E, 2, 1);                         \
-        } else if (no == 4) DVQ_PG_LAUNCH3(DVQ_BF16, E, 4, 2);             \
-        else DVQ_PG_LAUNCH3(DVQ_BF16, E, 2, 2);                            \
+            if (no == 4) DVQ_PG_LAUNCH3(DVQ_F32, E, 4, 1, 1);              \
+            else DVQ_PG_LAUNCH3(DVQ_F32, E, 2, 1, 1);                      \
+        } else if (no == 4) DVQ_PG_LAUNCH3(DVQ_BF16, E, 4, 2, 1);          \
+        else if (eight) DVQ_PG_LAUNCH3(DVQ_BF16, E, 2, 2, 2);              \
+        else DVQ_PG_LAUNCH3(DVQ_BF16, E, 2, 2, 1);                         \
     } while (0)
     if (epilogue == PG_PACK) DVQ_PG_LAUNCH(PG_PACK);
     else if (epilogue == PG_GATE) DVQ_PG_LAUNCH(PG_GATE);
