@@ -906,6 +906,16 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
     const bool eight = no == 2 && dtype == DVQ_BF16 && (N % 128) == 0 && (epilogue != PG_GATE || (N % 256) == 0) &&
                        (int64_t)(N / 128) * gy * n_jobs >= kNumCU;
     const int fg = eight ? 2 : 1;
+    // the residual 1x1 products are too small for two 64-wide workgroups per CU: 32-wide tiles (neutral at 4096 rows,
+    // 5.46 -> 5.32 ms per 2048 grids)
+    const bool one = !eight && no == 2 && dtype == DVQ_BF16 && epilogue == PG_PACK && (int64_t)(N / 64) * gy * n_jobs < want;
+    if (one) {
+        const dim3 grid1(N / 32, gy, n_jobs);
+        const size_t lds1 = (size_t)kPgRing * (1 * ks * upb + 4 * ks * upb) * 1024;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_gemm_kernel<DVQ_BF16, PG_PACK, 1, 2, 1>), lds1, "prior_gemm")) return rc;
+        hipLaunchKernelGGL((prior_gemm_kernel<DVQ_BF16, PG_PACK, 1, 2, 1>), grid1, dim3(256), lds1, st, dev, M, N, relu);
+        return check_launch("prior_gemm");
+    }
     const dim3 grid(N / (32 * no * fg), gy, n_jobs);
     const size_t lds = (size_t)kPgRing * (fg * no * ks * upb + 4 * ks * upb) * 1024;
     const dim3 blk(4 * fg * 64);
