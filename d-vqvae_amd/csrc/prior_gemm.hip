@@ -184,9 +184,10 @@ __device__ __forceinline__ void pg_epilogue(const PgJobDev& job, const Acc& acc,
     }
 }
 
-// Up to 32 rows (one sample tile; the reference samples one grid at a time): the product is a stream of weights
-// with next to no arithmetic, so it is cut along k instead of along the samples.  A workgroup of eight waves owns
-// one output-feature block (GATE: a block and its partner in the upper half); wave w takes the 1-KiB units
+// Small batches (the reference samples one grid at a time; used up to 512 rows in bf16, 1024 in fp32): the product is
+// a stream of weights with little arithmetic, so it is cut along k instead of along the samples.  A workgroup of
+// eight waves owns one sample tile and one output-feature block (GATE: a block and its partner in the upper half);
+// wave w takes the 1-KiB units
 // u = w, w+8, ... of every tap -- weights and activations of a tap are both contiguous in u -- straight from
 // global memory into MFMA operands, the eight partial tiles meet in LDS and are summed in wave order (the same
 // order every time), and the first wave runs the epilogue.  N/32 (N/64) workgroups per job stream the weights
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(kPgSmallWaves * 64) void prior_gemm_small_kernel(Pg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_ob = N / 32;
+    const int SB = gridDim.y, sb = blockIdx.y;               // one sample tile per workgroup
     int ob[NO];
     ob[0] = blockIdx.x;
     if (NO == 2) ob[1] = n_ob / 2 + blockIdx.x;
@@ -211,18 +213,20 @@ __global__ __launch_bounds__(kPgSmallWaves * 64) void prior_gemm_small_kernel(Pg
         for (int i = 0; i < 16; ++i) acc[t][0][i] = 0.f;
     for (int tp = 0; tp < job.n_taps; ++tp) {
         const int units = job.taps[tp].kb * UPB;
-        const char* x = job.taps[tp].x + lane * 16;
+        // activation unit (k-block, q) of this sample tile sits at ((k-block * SB + sb) * UPB + q)
+        const char* x = job.taps[tp].x + ((int64_t)sb * UPB) * 1024 + lane * 16;
+        const int64_t xstep = (int64_t)(SB - 1) * UPB;       // extra units skipped per k-block
         const char* w0 = job.taps[tp].w + (int64_t)ob[0] * units * 1024 + lane * 16;
         const char* w1 = job.taps[tp].w + (int64_t)ob[NO - 1] * units * 1024 + lane * 16;
 #pragma unroll 4
         for (int u = wave; u < units; u += kPgSmallWaves) {
             if constexpr (DT == DVQ_BF16) {
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(x + (int64_t)u * 1024);
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(x + ((int64_t)u + (u / UPB) * xstep) * 1024);
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(w0 + (int64_t)u * 1024), xf, acc[0][0], 0, 0, 0);
                 if (NO == 2)
                     acc[NO - 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(w1 + (int64_t)u * 1024), xf, acc[NO - 1][0], 0, 0, 0);
             } else {
-                const f32x4 xf = *reinterpret_cast<const f32x4*>(x + (int64_t)u * 1024);
+                const f32x4 xf = *reinterpret_cast<const f32x4*>(x + ((int64_t)u + (u / UPB) * xstep) * 1024);
                 const f32x4 wa = *reinterpret_cast<const f32x4*>(w0 + (int64_t)u * 1024);
                 f32x4 wb = wa;
                 if (NO == 2) wb = *reinterpret_cast<const f32x4*>(w1 + (int64_t)u * 1024);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(kPgSmallWaves * 64) void prior_gemm_small_kernel(Pg
             for (int w = 1; w < kPgSmallWaves; ++w) v += part[w][t][i][lane];
             acc[t][0][i] = v;
         }
-    pg_epilogue<DT, EPI, NO>(job, acc, ob, 0, lane, M, N, 1, relu);
+    pg_epilogue<DT, EPI, NO>(job, acc, ob, sb, lane, M, N, SB, relu);
 }
 
 // grid: x = output-feature group (FG x NO tiles of 32; for GATE half of them + the matching half of the upper
@@ -876,8 +880,13 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
     }
     const int SB = (M + 31) / 32;
     hipStream_t st = as_stream(stream);
-    if (SB == 1) {   // one sample tile: k-split kernel
-        const dim3 grid(epilogue == PG_GATE ? N / 64 : N / 32, 1, n_jobs), blk(kPgSmallWaves * 64);
+    // Few sample tiles: k-split kernel, one workgroup per (feature block, sample tile).  Whole tiles leave most CUs
+    // without work there (a 256-row gate product is 32 workgroups); the price is the weights read once per sample
+    // tile.  Per 9-cell sampling pass: 64..256 rows 4.0-4.1 -> 2.4-2.6 ms (bf16), 15.3 -> 5.6-6.3 ms (fp32);
+    // 512 rows 4.2 -> 3.3 / 15.6 -> 7.7 ms; 1024 rows 4.4 -> 5.3 (bf16: tiles stay) / 16.7 -> 13.9 ms.
+    const int small_sb = dtype == DVQ_F32 ? 32 : 16;
+    if (SB <= small_sb) {
+        const dim3 grid(epilogue == PG_GATE ? N / 64 : N / 32, SB, n_jobs), blk(kPgSmallWaves * 64);
 #define DVQ_PG_SMALL(E)                                                                                                     \
     do {                                                                                                                    \
         if (dtype == DVQ_F32) hipLaunchKernelGGL((prior_gemm_small_kernel<DVQ_F32, E>), grid, blk, 0, st, dev, M, N, relu); \

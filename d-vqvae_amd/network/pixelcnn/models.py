@@ -337,7 +337,8 @@ class GatedPixelCNN(nn.Module):
     # grid row 0 (nothing above it) and the whole of cell (0, 0) (nothing left of it), logits included.  Like the
     # packed weights they are constants of the checkpoint: evaluated for ONE row per class with the same kernels when
     # the weights are first used (_class_rows) and handed out to the rows of a batch by their label
-    # (_first_row_by_class) -- bit-equal to evaluating every row.  The rest of grid row 0 reads the row's vertical
+    # (_first_row_by_class) -- equal to evaluating every row (to the bit when the batch takes the same product
+    # kernel as the 128 class rows, to fp32 rounding otherwise).  The rest of grid row 0 reads the row's vertical
     # features only through their 1x1 projection into the gate: that projection, per class as well, is added to the
     # class-embedding table those cells' gate epilogue looks up, so the tap and the copies of the features go.
     def _by_class(self, B):
