@@ -25,6 +25,9 @@
 // tiles (shared through LDS) with one sample tile (four waves, or eight in two feature groups).
 #include "common.h"
 
+#ifndef DVQ_PG_RING8
+#define DVQ_PG_RING8 3
+#endif
 namespace dvq {
 
 constexpr int kPgWaves = 4;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(4 * FG * 64) void prior_gemm_kernel(PgJobs jobs, in
     constexpr int W_UNITS = FG * NO * KU;
     constexpr int X_UNITS = 4 * KU;
     constexpr int STAGE_BYTES = (W_UNITS + X_UNITS) * 1024;
-    constexpr int R = kPgRing;
+    constexpr int R = FG == 2 ? DVQ_PG_RING8 : kPgRing;
     static_assert(W_UNITS % WV == 0 && X_UNITS % WV == 0, "a stage's units are dealt evenly to the waves");
     constexpr int GLDS_PER_STAGE = (W_UNITS + X_UNITS) / WV;     // per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -322,17 +325,19 @@ __global__ __launch_bounds__(4 * FG * 64) void prior_gemm_kernel(PgJobs jobs, in
     int total_stages = 0;
     for (int t = 0; t < job.n_taps; ++t) total_stages += job.taps[t].kb / KS;
 
+    // operands of the tap whose stages are being issued (fetched from the job when the tap changes, not per stage)
+    int itap = 0, ikb = 0;   // next stage to issue
+    const char* tw = job.taps[0].w;
+    const char* tx = job.taps[0].x;
+    int tkb = job.taps[0].kb;
     // one stage: W units [group][t][k][s2] then X units [sample tile][k][s2], dealt to the waves unit by unit
-    auto issue = [&](int tap, int kb0, int buf) {
-        const char* w = job.taps[tap].w;
-        const char* x = job.taps[tap].x;
-        const int KB = job.taps[tap].kb;
+    auto issue = [&](int buf) {
         char* dst = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < W_UNITS / WV; ++i) {
             const int u = wave + WV * i;
             const int gt = u / KU, q = u % KU;
-            pg_glds16(w + ((int64_t)(block_of(gt / NO, gt % NO) * KB + kb0) * UPB + q) * 1024 + lane * 16, dst + u * 1024);
+            pg_glds16(tw + ((int64_t)(block_of(gt / NO, gt % NO) * tkb + ikb) * UPB + q) * 1024 + lane * 16, dst + u * 1024);
         }
 #pragma unroll
         for (int i = 0; i < X_UNITS / WV; ++i) {
@@ -340,21 +345,24 @@ __global__ __launch_bounds__(4 * FG * 64) void prior_gemm_kernel(PgJobs jobs, in
             const int tile = u / KU, q = u % KU;
             int sbt = by * 4 + tile;
             if (sbt >= SB) sbt = SB - 1;
-            pg_glds16(x + (((int64_t)(kb0 + q / UPB) * SB + sbt) * UPB + (q % UPB)) * 1024 + lane * 16,
+            pg_glds16(tx + (((int64_t)(ikb + q / UPB) * SB + sbt) * UPB + (q % UPB)) * 1024 + lane * 16,
                       dst + (W_UNITS + u) * 1024);
         }
-    };
-    auto advance = [&](int& tp, int& k0) {
-        k0 += KS;
-        if (k0 >= job.taps[tp].kb) { k0 = 0; ++tp; }
+        ikb += KS;
+        if (ikb >= tkb) {
+            ikb = 0;
+            ++itap;
+            if (itap < job.n_taps) {
+                tw = job.taps[itap].w; tx = job.taps[itap].x; tkb = job.taps[itap].kb;
+                // the scalar loads complete here, at the tap change, not behind the next stage's fragment reads
+                // (scalar loads and LDS reads share one counter)
+                asm volatile("" ::"s"(tw), "s"(tx), "s"(tkb));
+            }
+        }
     };
 
-    int itap = 0, ikb = 0;   // next stage to issue
     int issued = 0;
-    for (; issued < R - 1 && issued < total_stages; ++issued) {
-        issue(itap, ikb, issued % R);
-        advance(itap, ikb);
-    }
+    for (; issued < R - 1 && issued < total_stages; ++issued) issue(issued % R);
     for (int st = 0; st < total_stages; ++st) {
         // this wave's loads of stage st have landed when at most `younger` stages' worth are outstanding
         const int younger = issued - st - 1;
@@ -362,31 +370,41 @@ __global__ __launch_bounds__(4 * FG * 64) void prior_gemm_kernel(PgJobs jobs, in
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(GLDS_PER_STAGE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (issued < total_stages) {   // refill the buffer every wave finished reading before this barrier
-            issue(itap, ikb, issued % R);
-            advance(itap, ikb);
-            ++issued;
-        }
+        // All fragment reads of the stage go out first, the refill of the buffer every wave finished reading before
+        // this barrier is issued behind them (its issue time then covers the LDS latency), the products last.
         const char* sbuf = smem + (st % R) * STAGE_BYTES + lane * 16;
+        if constexpr (DT == DVQ_BF16) {
+            bf16x8 xf[KU], wfr[NO][KU];
 #pragma unroll
-        for (int q = 0; q < KU; ++q) {
-            if constexpr (DT == DVQ_BF16) {
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sbuf + (W_UNITS + ws * KU + q) * 1024);
+            for (int q = 0; q < KU; ++q) {
+                xf[q] = *reinterpret_cast<const bf16x8*>(sbuf + (W_UNITS + ws * KU + q) * 1024);
 #pragma unroll
-                for (int t = 0; t < NO; ++t) {
-                    const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(sbuf + ((wf * NO + t) * KU + q) * 1024);
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, xf, acc[t][0], 0, 0, 0);
-                }
-            } else {
-                const f32x4 xf = *reinterpret_cast<const f32x4*>(sbuf + (W_UNITS + ws * KU + q) * 1024);
-                f32x4 wfr[NO];
+                for (int t = 0; t < NO; ++t) wfr[t][q] = *reinterpret_cast<const bf16x8*>(sbuf + ((wf * NO + t) * KU + q) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (issued < total_stages) { issue(issued % R); ++issued; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < NO; ++t) wfr[t] = *reinterpret_cast<const f32x4*>(sbuf + ((wf * NO + t) * KU + q) * 1024);
+            for (int q = 0; q < KU; ++q)
+#pragma unroll
+                for (int t = 0; t < NO; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[t][q], xf[q], acc[t][0], 0, 0, 0);
+        } else {
+            f32x4 xf[KU], wfr[NO][KU];
+#pragma unroll
+            for (int q = 0; q < KU; ++q) {
+                xf[q] = *reinterpret_cast<const f32x4*>(sbuf + (W_UNITS + ws * KU + q) * 1024);
+#pragma unroll
+                for (int t = 0; t < NO; ++t) wfr[t][q] = *reinterpret_cast<const f32x4*>(sbuf + ((wf * NO + t) * KU + q) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (issued < total_stages) { issue(issued % R); ++issued; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < KU; ++q)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int t = 0; t < NO; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[t][j], xf[j], acc[t][0], 0, 0, 0);
-            }
+                    for (int t = 0; t < NO; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[t][q][j], xf[q][j], acc[t][0], 0, 0, 0);
         }
     }
 
@@ -926,7 +944,7 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
         return check_launch("prior_gemm");
     }
     const dim3 grid(N / (32 * no * fg), gy, n_jobs);
-    const size_t lds = (size_t)kPgRing * (fg * no * ks * upb + 4 * ks * upb) * 1024;
+    const size_t lds = (size_t)(eight ? DVQ_PG_RING8 : kPgRing) * (fg * no * ks * upb + 4 * ks * upb) * 1024;
     const dim3 blk(4 * fg * 64);
 #define DVQ_PG_LAUNCH3(D, E, NO_, KS_, FG_)                                                                   \
     do {                                                                                                 \
