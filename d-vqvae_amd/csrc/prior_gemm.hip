@@ -570,58 +570,84 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int
             for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.f;
 
     const int total_stages = d.n_rows * KB;
-    auto issue = [&](int st) {
-        const int row = st / KB, kb0 = st - row * KB;
-        char* dst = smem + (st % R) * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < W_UNITS / kPgWaves; ++i) {
+    // operand pointers of both input rows, held in registers (indexing the descriptor by the row inside the loop
+    // would fetch them with scalar loads every stage, and their wait also waits for the LDS reads in flight)
+    const char* w0[3] = {d.w[0][0], d.w[0][1], d.w[0][2]};
+    const char* w1[3] = {d.w[1][0], d.w[1][1], d.w[1][2]};
+    const char* x0[3] = {d.x[0][0], d.x[0][1], d.x[0][2]};
+    const char* x1[3] = {d.x[1][0], d.x[1][1], d.x[1][2]};
+    int irow = 0, ikb = 0, issued = 0;       // next stage to issue
+    // piece i (0..11) of the stage being issued: six weight units, then this wave's six activation units
+    auto piece = [&](int i) {
+        char* dst = smem + (issued % R) * STAGE_BYTES;
+        if (i < W_UNITS / kPgWaves) {
             const int u = wave + kPgWaves * i;               // u = (tap * NO + t) * 2 + q
             const int tap = u / (NO * 2), t = (u / 2) % NO, q = u & 1;
-            pg_glds16(d.w[row][tap] + ((int64_t)(ob[t] * KB + kb0) * 2 + q) * 1024 + lane * 16, dst + u * 1024);
+            const int blk = (t >> 1) * half + 2 * bx + (t & 1);
+            const char* wp = irow ? (tap == 0 ? w1[0] : tap == 1 ? w1[1] : w1[2]) : (tap == 0 ? w0[0] : tap == 1 ? w0[1] : w0[2]);
+            pg_glds16(wp + ((int64_t)(blk * KB + ikb) * 2 + q) * 1024 + lane * 16, dst + u * 1024);
+        } else {
+            const int k = i - W_UNITS / kPgWaves, col = k >> 1, q = k & 1;
+            const char* xp = irow ? x1[col] : x0[col];
+            pg_glds16(xp + (((int64_t)ikb * SB + sb) * 2 + q) * 1024 + lane * 16,
+                      dst + (W_UNITS + (col * kPgWaves + wave) * 2 + q) * 1024);
         }
-#pragma unroll
-        for (int col = 0; col < 3; ++col)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                pg_glds16(d.x[row][col] + (((int64_t)kb0 * SB + sb) * 2 + q) * 1024 + lane * 16,
-                          dst + (W_UNITS + (col * kPgWaves + wave) * 2 + q) * 1024);
+    };
+    auto issued_one = [&]() {
+        ++issued;
+        if (++ikb == KB) { ikb = 0; ++irow; }
     };
 
-    int issued = 0;
-    for (; issued < R - 1 && issued < total_stages; ++issued) issue(issued);
+    for (int s0 = 0; s0 < R - 1 && s0 < total_stages; ++s0) {
+#pragma unroll
+        for (int i = 0; i < GLDS_PER_STAGE; ++i) piece(i);
+        issued_one();
+    }
     for (int st = 0; st < total_stages; ++st) {
         if (issued - st - 1 >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(GLDS_PER_STAGE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (issued < total_stages) { issue(issued); ++issued; }
+        const bool refill = issued < total_stages;   // into the buffer every wave finished reading before this barrier
         const char* sbuf = smem + (st % R) * STAGE_BYTES + lane * 16;
-        // 2 x 12 weight fragments per stage, each feeding two or three MFMAs; a fragment is read one item ahead of
-        // its use so that the LDS traffic (30 KiB per wave and stage) runs under the matrix pipe, not before it
+        // A stage is 2 x 12 weight fragments, each feeding two or three MFMAs.  The fragments of the first k-half are
+        // read together, those of the second one per item under the first half's MFMAs; the twelve refill copies are
+        // dealt between the items, so that neither the LDS latency nor the issue time of a copy (60-180 cycles each)
+        // stands before the matrix pipe with nothing in it.
         auto xaddr = [&](int q, int col) { return sbuf + (W_UNITS + (col * kPgWaves + wave) * 2 + q) * 1024; };
-        auto waddr = [&](int item) {   // item = q * 12 + tap * NO + t
-            const int q = item / (3 * NO), r = item % (3 * NO);
-            return sbuf + (r * 2 + q) * 1024;
-        };
-        bf16x8 xf[3], wq[2];
+        auto waddr = [&](int q, int r) { return sbuf + (r * 2 + q) * 1024; };   // r = tap * NO + t
+        bf16x8 xa[3], xb[3], wa[3 * NO], wb[3 * NO];
 #pragma unroll
-        for (int col = 0; col < 3; ++col) xf[col] = *reinterpret_cast<const bf16x8*>(xaddr(0, col));
-        wq[0] = *reinterpret_cast<const bf16x8*>(waddr(0));
+        for (int col = 0; col < 3; ++col) xa[col] = *reinterpret_cast<const bf16x8*>(xaddr(0, col));
 #pragma unroll
-        for (int item = 0; item < 2 * 3 * NO; ++item) {
-            const int q = item / (3 * NO), tap = (item % (3 * NO)) / NO, t = item % NO;
-            if (item + 1 < 2 * 3 * NO) wq[(item + 1) & 1] = *reinterpret_cast<const bf16x8*>(waddr(item + 1));
+        for (int r = 0; r < 3 * NO; ++r) wa[r] = *reinterpret_cast<const bf16x8*>(waddr(0, r));
+        __builtin_amdgcn_sched_barrier(0);
+        if (refill) { piece(0); piece(1); piece(2); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 3 * NO; ++r) {
+            const int tap = r / NO, t = r % NO;
+            if (r < 3) xb[r] = *reinterpret_cast<const bf16x8*>(xaddr(1, r));
+            wb[r] = *reinterpret_cast<const bf16x8*>(waddr(1, r));
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int col = j + tap - 1;       // tap <-> column offset tap - 1: cell j reads column j + tap - 1
-                if (col >= 0 && col < 3) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[item & 1], xf[col], acc[j][t], 0, 0, 0);
+                if (col >= 0 && col < 3) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[r], xa[col], acc[j][t], 0, 0, 0);
             }
-            if (item == 3 * NO - 1) {              // last item of q = 0: its activations are dead, fetch those of q = 1
-#pragma unroll
-                for (int col = 0; col < 3; ++col) xf[col] = *reinterpret_cast<const bf16x8*>(xaddr(1, col));
-            }
-            (void)q;
+            if ((r & 1) && refill) piece(3 + (r >> 1));          // pieces 3..8
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int r = 0; r < 3 * NO; ++r) {
+            const int tap = r / NO, t = r % NO;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int col = j + tap - 1;
+                if (col >= 0 && col < 3) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[r], xb[col], acc[j][t], 0, 0, 0);
+            }
+            if (r < 3 && refill) piece(9 + r);                   // pieces 9..11
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (refill) issued_one();
     }
 
     if (!live) return;
