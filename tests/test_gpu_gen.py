@@ -212,6 +212,42 @@ def test_prior_vrow_kernel_equals_three_per_cell_products():
             assert (fa != fb).float().mean().item() < 0.05
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prior_products_tiled_and_k_split_kernels_agree(dtype):
+    """dvq_prior_gemm takes whole 128-sample tiles for large batches and the k-split kernel (one workgroup per 32-sample
+    tile) for small ones.  The same rows through both -- a ragged 1100-row batch on the tiles, its first 64 and its last
+    12 rows on the k-split kernel -- against each other and against an fp64 product of the operands as the kernels see
+    them (fp32, or rounded to bf16): the two differ only in the order of the fp32 sums."""
+    from dvq_hip import ops
+    code = ops.DVQ_BF16 if dtype == torch.bfloat16 else ops.DVQ_F32
+    g = torch.Generator(DEV).manual_seed(12)
+    V, d, N, M = 70, 128, 256, 1100
+    table = torch.randn(V, d, device=DEV, generator=g)
+    idx = [torch.randint(0, V, (M,), device=DEV, generator=g) for _ in range(2)]
+    W = [torch.randn(N, d, device=DEV, generator=g) * 0.1 for _ in range(2)]
+    bias = torch.randn(N, device=DEV, generator=g)
+    Wp = [ops.prior_pack_weight(w, code) for w in W]
+
+    def rows(sel):
+        m = sel.stop - sel.start
+        xs = [ops.prior_embed(i[sel].contiguous(), table, ops.prior_packed_empty(m, d, DEV, True, code), code) for i in idx]
+        out = torch.empty(m, N, dtype=torch.float32, device=DEV)
+        ops.prior_gemm([ops.prior_job([(xs[0], Wp[0], d // 32), (xs[1], Wp[1], d // 32)], bias, out_rows=out)], m, N,
+                       ops.PRIOR_ROWS, False, table, code)
+        return out
+
+    big = rows(slice(0, M))
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if dtype == torch.bfloat16 else (lambda t: t.double())
+    want = sum(rnd(table)[i] @ rnd(w).T for i, w in zip(idx, W)) + bias.double()
+    tol = 2e-5 * want.abs().max().item()
+    assert (big.double() - want).abs().max().item() <= tol
+    for sel in (slice(0, 64), slice(M - 12, M)):
+        small = rows(sel)
+        assert (small.double() - want[sel]).abs().max().item() <= tol
+        assert (small - big[sel]).abs().max().item() <= tol
+
+
 def test_prior_sample_kernel_equals_softmax_cumsum_searchsorted():
     """The fused cell sampler against the torch formulation it replaces (softmax, renormalise, fp64 cumulative
     sum, searchsorted) and against prior_embed for the packed embedding rows."""
