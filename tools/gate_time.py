@@ -1,6 +1,6 @@
 """Time of the prior's gate product launched alone (the bench's roofline_prior leg), for ablation builds."""
 import os, sys
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "d-vqvae_amd")); sys.path.insert(0, ROOT)
 import torch
 import bench

@@ -1,6 +1,6 @@
 """Time of the fused vertical-row kernel launched alone at the prior's shape (4096 rows, 512 -> 1024 features, two input rows)."""
 import os, sys
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "d-vqvae_amd"))
 import torch
 from dvq_hip import ops
