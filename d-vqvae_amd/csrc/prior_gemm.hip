@@ -523,8 +523,8 @@ __global__ __launch_bounds__(256) void prior_gather_rows_kernel(PgGatherList lis
 // cells, so a workgroup that owns a 128-sample x 128-feature tile of ALL THREE cells loads each activation unit
 // and each weight unit once per k-block instead of once per cell: 149 FLOP per byte moved from L2 against 64 for
 // the per-cell product above, which is what bounds it.  Stage = one input row x one k-block: 3 columns of
-// activations (2 units per wave each) + 3 taps of weights (NO x 2 units each), 48 KiB, ring of three.
-// (The same tile on eight waves -- two feature groups, 164 registers, two waves per SIMD -- runs at the same speed.)
+// activations (4 sample tiles x 2 units each) + 3 taps of weights (4 feature tiles x 2 units each), 48 KiB, ring of three.
+// The tile is shared by 4 x FG waves: wave (ws, wf) owns sample tile ws and the 4 / FG feature tiles of group wf.
 struct PvDesc {
     const char* x[2][3];
     const char* w[2][3];
@@ -537,26 +537,35 @@ struct PvDesc {
     char* out_pre[3];
 };
 
-__global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int M, int N) {
+template <int FG>
+__global__ __launch_bounds__(4 * FG * 64) void prior_vrow_kernel(PvDesc d, int M, int N) {
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NO = 4;
-    constexpr int W_UNITS = 3 * NO * 2;                      // [tap][t][q]
-    constexpr int X_UNITS = 3 * kPgWaves * 2;                // [col][wave][q]
+    constexpr int WV = 4 * FG;                               // waves: 4 sample tiles x FG feature groups
+    constexpr int NO = 4 / FG;                               // feature tiles per wave (half tanh, half sigmoid blocks)
+    constexpr int W_UNITS = 3 * 4 * 2;                       // [tap][group * NO + t][q]
+    constexpr int X_UNITS = 3 * 4 * 2;                       // [col][sample tile][q]
     constexpr int STAGE_BYTES = (W_UNITS + X_UNITS) * 1024;
     constexpr int R = 3;
-    constexpr int GLDS_PER_STAGE = W_UNITS / kPgWaves + 6;   // per wave
+    constexpr int PW = W_UNITS / WV, PX = X_UNITS / WV;      // copies per wave and stage
+    constexpr int GLDS_PER_STAGE = PW + PX;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wave & 3, wf = wave >> 2;
     const int c = lane & 31, h = lane >> 5;
     const int SB = (M + 31) / 32;
     const int n_ob = N / 32, half = n_ob / 2;
     int bx, by;
     xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    // output-feature block of tile gt (0..3) of the workgroup: group gt / NO, its tile gt % NO
+    auto block_of = [&](int gt) {
+        const int g = gt / NO, t = gt % NO;
+        return (t < NO / 2 ? 0 : half) + 2 * bx + g * (NO / 2) + t % (NO / 2);
+    };
     int ob[NO];
 #pragma unroll
-    for (int t = 0; t < NO / 2; ++t) { ob[t] = (NO / 2) * bx + t; ob[t + NO / 2] = half + (NO / 2) * bx + t; }
-    int sb = by * kPgWaves + wave;
+    for (int t = 0; t < NO; ++t) ob[t] = block_of(wf * NO + t);
+    int sb = by * 4 + ws;
     const bool live = sb < SB;
     if (!live) sb = SB - 1;
     const int KB = d.kb;
@@ -577,20 +586,21 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int
     const char* x0[3] = {d.x[0][0], d.x[0][1], d.x[0][2]};
     const char* x1[3] = {d.x[1][0], d.x[1][1], d.x[1][2]};
     int irow = 0, ikb = 0, issued = 0;       // next stage to issue
-    // piece i (0..11) of the stage being issued: six weight units, then this wave's six activation units
+    // piece i of the stage being issued: this wave's share of the weight units, then of the activation units
     auto piece = [&](int i) {
         char* dst = smem + (issued % R) * STAGE_BYTES;
-        if (i < W_UNITS / kPgWaves) {
-            const int u = wave + kPgWaves * i;               // u = (tap * NO + t) * 2 + q
-            const int tap = u / (NO * 2), t = (u / 2) % NO, q = u & 1;
-            const int blk = (t >> 1) * half + 2 * bx + (t & 1);
+        if (i < PW) {
+            const int u = wave + WV * i;                     // u = (tap * 4 + group * NO + t) * 2 + q
+            const int tap = u / 8, gt = (u / 2) % 4, q = u & 1;
             const char* wp = irow ? (tap == 0 ? w1[0] : tap == 1 ? w1[1] : w1[2]) : (tap == 0 ? w0[0] : tap == 1 ? w0[1] : w0[2]);
-            pg_glds16(wp + ((int64_t)(blk * KB + ikb) * 2 + q) * 1024 + lane * 16, dst + u * 1024);
+            pg_glds16(wp + ((int64_t)(block_of(gt) * KB + ikb) * 2 + q) * 1024 + lane * 16, dst + u * 1024);
         } else {
-            const int k = i - W_UNITS / kPgWaves, col = k >> 1, q = k & 1;
-            const char* xp = irow ? x1[col] : x0[col];
-            pg_glds16(xp + (((int64_t)ikb * SB + sb) * 2 + q) * 1024 + lane * 16,
-                      dst + (W_UNITS + (col * kPgWaves + wave) * 2 + q) * 1024);
+            const int u = wave + WV * (i - PW);              // u = (col * 4 + sample tile) * 2 + q
+            const int col = u / 8, tile = (u / 2) % 4, q = u & 1;
+            int sbt = by * 4 + tile;
+            if (sbt >= SB) sbt = SB - 1;
+            const char* xp = irow ? (col == 0 ? x1[0] : col == 1 ? x1[1] : x1[2]) : (col == 0 ? x0[0] : col == 1 ? x0[1] : x0[2]);
+            pg_glds16(xp + (((int64_t)ikb * SB + sbt) * 2 + q) * 1024 + lane * 16, dst + (W_UNITS + u) * 1024);
         }
     };
     auto issued_one = [&]() {
@@ -613,15 +623,18 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int
         // read together, those of the second one per item under the first half's MFMAs; the twelve refill copies are
         // dealt between the items, so that neither the LDS latency nor the issue time of a copy (60-180 cycles each)
         // stands before the matrix pipe with nothing in it.
-        auto xaddr = [&](int q, int col) { return sbuf + (W_UNITS + (col * kPgWaves + wave) * 2 + q) * 1024; };
-        auto waddr = [&](int q, int r) { return sbuf + (r * 2 + q) * 1024; };   // r = tap * NO + t
+        auto xaddr = [&](int q, int col) { return sbuf + (W_UNITS + (col * 4 + ws) * 2 + q) * 1024; };
+        auto waddr = [&](int q, int r) { return sbuf + (((r / NO) * 4 + wf * NO + r % NO) * 2 + q) * 1024; };   // r = tap * NO + t
         bf16x8 xa[3], xb[3], wa[3 * NO], wb[3 * NO];
 #pragma unroll
         for (int col = 0; col < 3; ++col) xa[col] = *reinterpret_cast<const bf16x8*>(xaddr(0, col));
 #pragma unroll
         for (int r = 0; r < 3 * NO; ++r) wa[r] = *reinterpret_cast<const bf16x8*>(waddr(0, r));
         __builtin_amdgcn_sched_barrier(0);
-        if (refill) { piece(0); piece(1); piece(2); }
+        if (refill) {
+#pragma unroll
+            for (int i = 0; i < 3 && i < GLDS_PER_STAGE; ++i) piece(i);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 3 * NO; ++r) {
@@ -633,7 +646,7 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int
                 const int col = j + tap - 1;       // tap <-> column offset tap - 1: cell j reads column j + tap - 1
                 if (col >= 0 && col < 3) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[r], xa[col], acc[j][t], 0, 0, 0);
             }
-            if ((r & 1) && refill) piece(3 + (r >> 1));          // pieces 3..8
+            if ((r & 1) && 3 + (r >> 1) < GLDS_PER_STAGE && refill) piece(3 + (r >> 1));
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -644,7 +657,7 @@ __global__ __launch_bounds__(kPgWaves * 64) void prior_vrow_kernel(PvDesc d, int
                 const int col = j + tap - 1;
                 if (col >= 0 && col < 3) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[r], xb[col], acc[j][t], 0, 0, 0);
             }
-            if (r < 3 && refill) piece(9 + r);                   // pieces 9..11
+            if (3 + (3 * NO) / 2 + r < GLDS_PER_STAGE && refill) piece(3 + (3 * NO) / 2 + r);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (refill) issued_one();
@@ -873,10 +886,12 @@ extern "C" int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream)
     }
     d.n_rows = v->n_rows; d.kb = v->k_blocks; d.bias = v->bias; d.cond = v->cond; d.label = v->label;
     const int SB = (M + 31) / 32;
-    const dim3 grid(N / 128, (SB + kPgWaves - 1) / kPgWaves);
-    const size_t lds = (size_t)3 * (3 * 4 * 2 + 3 * kPgWaves * 2) * 1024;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_vrow_kernel), lds, "prior_vrow")) return rc;
-    hipLaunchKernelGGL(prior_vrow_kernel, grid, dim3(kPgWaves * 64), lds, as_stream(stream), d, M, N);
+    const dim3 grid(N / 128, (SB + 3) / 4);
+    const size_t lds = (size_t)3 * (3 * 4 * 2 + 3 * 4 * 2) * 1024;
+    // eight waves (two feature groups, 164 registers, two waves per SIMD): 69.5 -> 66 us per launch against four waves
+    // with all four feature tiles each (FG = 1: 448 registers, one wave per SIMD)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_vrow_kernel<2>), lds, "prior_vrow")) return rc;
+    hipLaunchKernelGGL(prior_vrow_kernel<2>, grid, dim3(512), lds, as_stream(stream), d, M, N);
     return check_launch("prior_vrow");
 }
 
