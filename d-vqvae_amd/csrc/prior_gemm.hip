@@ -16,9 +16,9 @@
 // One product sums over several (activation, weight) pairs ("taps": kernel positions of a
 // masked convolution, or the horizontal stack's inputs) before its epilogue:
 //   PACK  y = acc + bias (+ residual) (relu)          -> packed bf16
-//   GATE  tanh(y[n]) * sigmoid(y[n+N/2]), y = acc + bias + class_embedding[label]
+//   GATE  tanh(y[n]) * sigmoid(y[n+N/2]), y = p + class_embedding[label], p = acc + bias (+ pre_add[label])
 //                                                      -> packed bf16 (N/2 features),
-//         optionally also y without the class term     -> packed bf16 (N features)
+//         optionally also p (y without the class term) -> packed bf16 (N features)
 //   ROWS  y = acc + bias (relu)                        -> fp32 [M, N] row-major (logits; heads)
 //
 // Tiling: a workgroup owns 4 sample tiles x 2..4 output-feature tiles; a wave multiplies NO weight
@@ -49,6 +49,7 @@ struct PgJobDev {
     char* out_packed;
     char* out_pre;
     float* out_rows;
+    const float* pre_add;
 };
 struct PgJobs {
     PgJobDev j[3];
@@ -119,9 +120,9 @@ __device__ __forceinline__ void pg_add_block(const char* base, int lane, float* 
 
 // Epilogue of one sample tile: acc[t] = tile of output-feature block ob[t] (for GATE: t < NO/2 the tanh half, the rest
 // the matching sigmoid half).  Register i of a tile <-> feature 32*ob + (i&3) + 8*(i>>2) + 4h, lane c <-> sample 32*sb + c.
-template <int DT, int EPI, int NO, typename Acc>
-__device__ __forceinline__ void pg_epilogue(const PgJobDev& job, const Acc& acc, const int* ob, int sb, int lane, int M, int N,
-                                            int SB, int relu) {
+template <int DT, int EPI, int NO, bool ADD, typename Acc>
+__device__ __forceinline__ void pg_epilogue_impl(const PgJobDev& job, const Acc& acc, const int* ob, int sb, int lane, int M,
+                                                 int N, int SB, int relu) {
     constexpr int UPB = PgT<DT>::UPB;
     const int c = lane & 31, h = lane >> 5;
     int m = sb * 32 + c;
@@ -129,14 +130,16 @@ __device__ __forceinline__ void pg_epilogue(const PgJobDev& job, const Acc& acc,
     if (!mvalid) m = M - 1;
     if (EPI == PG_GATE) {
         const float* crow = job.cond + job.label[m] * N;
+        const float* arow = ADD ? job.pre_add + job.label[m] * N : nullptr;
 #pragma unroll
         for (int t = 0; t < NO / 2; ++t) {
             float g[16], pre_lo[16], pre_hi[16];
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int nlo = 32 * ob[t] + 8 * q4 + 4 * h, nhi = 32 * ob[t + NO / 2] + 8 * q4 + 4 * h;
-                const f32x4 blo = *reinterpret_cast<const f32x4*>(job.bias + nlo);
-                const f32x4 bhi = *reinterpret_cast<const f32x4*>(job.bias + nhi);
+                f32x4 blo = *reinterpret_cast<const f32x4*>(job.bias + nlo);
+                f32x4 bhi = *reinterpret_cast<const f32x4*>(job.bias + nhi);
+                if constexpr (ADD) { blo += *reinterpret_cast<const f32x4*>(arow + nlo); bhi += *reinterpret_cast<const f32x4*>(arow + nhi); }
                 const f32x4 clo = *reinterpret_cast<const f32x4*>(crow + nlo);
                 const f32x4 chi = *reinterpret_cast<const f32x4*>(crow + nhi);
 #pragma unroll
@@ -185,6 +188,14 @@ __device__ __forceinline__ void pg_epilogue(const PgJobDev& job, const Acc& acc,
             }
         }
     }
+}
+
+// (two instantiations: with the optional per-class addend as a run-time branch the epilogue needed twice the registers)
+template <int DT, int EPI, int NO, typename Acc>
+__device__ __forceinline__ void pg_epilogue(const PgJobDev& job, const Acc& acc, const int* ob, int sb, int lane, int M, int N,
+                                            int SB, int relu) {
+    if (EPI == PG_GATE && job.pre_add) pg_epilogue_impl<DT, EPI, NO, true>(job, acc, ob, sb, lane, M, N, SB, relu);
+    else pg_epilogue_impl<DT, EPI, NO, false>(job, acc, ob, sb, lane, M, N, SB, relu);
 }
 
 // Small batches (the reference samples one grid at a time; used up to 512 rows in bf16, 1024 in fp32): the product is
@@ -532,6 +543,7 @@ struct PvDesc {
     int kb;
     const float* bias;
     const float* cond;
+    const float* pre_add[3];   // per cell, optional
     const int64_t* label;
     char* out_packed[3];
     char* out_pre[3];
@@ -666,37 +678,46 @@ __global__ __launch_bounds__(4 * FG * 64) void prior_vrow_kernel(PvDesc d, int M
     if (!live) return;
     int m = sb * 32 + c;
     if (m >= M) m = M - 1;
-    const float* crow = d.cond + d.label[m] * N;
+    const int64_t lab = d.label[m];
+    const float* crow = d.cond + lab * N;
+    auto epilogue = [&](auto add_const) {
+        constexpr bool ADD = decltype(add_const)::value;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 3; ++j) {
+            const float* arow = ADD ? d.pre_add[j] + lab * N : nullptr;
 #pragma unroll
-        for (int t = 0; t < NO / 2; ++t) {
-            float g[16], pre_lo[16], pre_hi[16];
+            for (int t = 0; t < NO / 2; ++t) {
+                float g[16], pre_lo[16], pre_hi[16];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int nlo = 32 * ob[t] + 8 * q4 + 4 * h, nhi = 32 * ob[t + NO / 2] + 8 * q4 + 4 * h;
-                const f32x4 blo = *reinterpret_cast<const f32x4*>(d.bias + nlo);
-                const f32x4 bhi = *reinterpret_cast<const f32x4*>(d.bias + nhi);
-                const f32x4 clo = *reinterpret_cast<const f32x4*>(crow + nlo);
-                const f32x4 chi = *reinterpret_cast<const f32x4*>(crow + nhi);
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int nlo = 32 * ob[t] + 8 * q4 + 4 * h, nhi = 32 * ob[t + NO / 2] + 8 * q4 + 4 * h;
+                    f32x4 blo = *reinterpret_cast<const f32x4*>(d.bias + nlo);
+                    f32x4 bhi = *reinterpret_cast<const f32x4*>(d.bias + nhi);
+                    if constexpr (ADD) { blo += *reinterpret_cast<const f32x4*>(arow + nlo); bhi += *reinterpret_cast<const f32x4*>(arow + nhi); }
+                    const f32x4 clo = *reinterpret_cast<const f32x4*>(crow + nlo);
+                    const f32x4 chi = *reinterpret_cast<const f32x4*>(crow + nhi);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 4 * q4 + q;
-                    pre_lo[i] = acc[j][t][i] + blo[q];
-                    pre_hi[i] = acc[j][t + NO / 2][i] + bhi[q];
-                    g[i] = fast_tanh(pre_lo[i] + clo[q]) * fast_sigmoid(pre_hi[i] + chi[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 4 * q4 + q;
+                        pre_lo[i] = acc[j][t][i] + blo[q];
+                        pre_hi[i] = acc[j][t + NO / 2][i] + bhi[q];
+                        g[i] = fast_tanh(pre_lo[i] + clo[q]) * fast_sigmoid(pre_hi[i] + chi[q]);
+                    }
                 }
-            }
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                *reinterpret_cast<uint4*>(d.out_packed[j] + (((int64_t)ob[t] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(g + 8 * s2);
-                if (d.out_pre[j]) {
-                    *reinterpret_cast<uint4*>(d.out_pre[j] + (((int64_t)ob[t] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(pre_lo + 8 * s2);
-                    *reinterpret_cast<uint4*>(d.out_pre[j] + (((int64_t)ob[t + NO / 2] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(pre_hi + 8 * s2);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    *reinterpret_cast<uint4*>(d.out_packed[j] + (((int64_t)ob[t] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(g + 8 * s2);
+                    if (d.out_pre[j]) {
+                        *reinterpret_cast<uint4*>(d.out_pre[j] + (((int64_t)ob[t] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(pre_lo + 8 * s2);
+                        *reinterpret_cast<uint4*>(d.out_pre[j] + (((int64_t)ob[t + NO / 2] * SB + sb) * 2 + s2) * 1024 + lane * 16) = pack8(pre_hi + 8 * s2);
+                    }
                 }
             }
         }
-    }
+    };
+    // (the per-class addend comes for all three cells or for none)
+    if (d.pre_add[0]) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // One grid cell of the sampling loop in a single launch (DVQ-VAE/network/pixelcnn/models.py:189-196): softmax of the
@@ -885,6 +906,9 @@ extern "C" int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream)
         d.out_pre[j] = reinterpret_cast<char*>(v->out_pre[j]);
     }
     d.n_rows = v->n_rows; d.kb = v->k_blocks; d.bias = v->bias; d.cond = v->cond; d.label = v->label;
+    for (int j = 0; j < 3; ++j) d.pre_add[j] = v->pre_add[j];
+    if ((v->pre_add[0] != nullptr) != (v->pre_add[1] != nullptr) || (v->pre_add[0] != nullptr) != (v->pre_add[2] != nullptr))
+        return fail(DVQ_EINVAL, "prior_vrow: pre_add must be given for all three cells or for none");
     const int SB = (M + 31) / 32;
     const dim3 grid(N / 128, (SB + 3) / 4);
     const size_t lds = (size_t)3 * (3 * 4 * 2 + 3 * 4 * 2) * 1024;
@@ -933,6 +957,7 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
         d.out_packed = reinterpret_cast<char*>(s.out_packed);
         d.out_pre = reinterpret_cast<char*>(s.out_pre);
         d.out_rows = s.out_rows;
+        d.pre_add = s.pre_add;
         if (epilogue == PG_GATE && (!s.cond || !s.label || !s.out_packed)) return fail(DVQ_EINVAL, "prior_gemm: gate needs cond, label, out_packed");
         if (epilogue == PG_PACK && !s.out_packed) return fail(DVQ_EINVAL, "prior_gemm: out_packed missing");
         if (epilogue == PG_ROWS && !s.out_rows) return fail(DVQ_EINVAL, "prior_gemm: out_rows missing");

@@ -46,13 +46,13 @@ class DvqPriorTap(ctypes.Structure):
 class DvqPriorJob(ctypes.Structure):
     _fields_ = [("taps", DvqPriorTap * 10), ("n_taps", c_int), ("bias", c_void_p), ("cond", c_void_p),
                 ("label", c_void_p), ("resid", c_void_p), ("out_packed", c_void_p), ("out_pre", c_void_p),
-                ("out_rows", c_void_p)]
+                ("out_rows", c_void_p), ("pre_add", c_void_p)]
 
 
 class DvqPriorVRow(ctypes.Structure):
     _fields_ = [("x", (c_void_p * 3) * 2), ("w", (c_void_p * 3) * 2), ("n_rows", c_int), ("k_blocks", c_int),
                 ("bias", c_void_p), ("cond", c_void_p), ("label", c_void_p), ("out_packed", c_void_p * 3),
-                ("out_pre", c_void_p * 3)]
+                ("out_pre", c_void_p * 3), ("pre_add", c_void_p * 3)]
 
 
 class DvqPriorGather(ctypes.Structure):

@@ -430,7 +430,8 @@ def prior_embed(idx: torch.Tensor, table: torch.Tensor, out: torch.Tensor, dtype
     return out
 
 
-def prior_job(taps, bias, cond=None, label=None, resid=None, out_packed=None, out_pre=None, out_rows=None) -> DvqPriorJob:
+def prior_job(taps, bias, cond=None, label=None, resid=None, out_packed=None, out_pre=None, out_rows=None,
+              pre_add=None) -> DvqPriorJob:
     """taps: list of (packed activations, packed weights, k_blocks)."""
     j = DvqPriorJob()
     if not 1 <= len(taps) <= 10:
@@ -440,7 +441,7 @@ def prior_job(taps, bias, cond=None, label=None, resid=None, out_packed=None, ou
     j.n_taps = len(taps)
     j.bias = bias.data_ptr()
     for name, t in (("cond", cond), ("label", label), ("resid", resid), ("out_packed", out_packed), ("out_pre", out_pre),
-                    ("out_rows", out_rows)):
+                    ("out_rows", out_rows), ("pre_add", pre_add)):
         setattr(j, name, t.data_ptr() if t is not None else None)
     return j
 
@@ -497,10 +498,11 @@ def prior_gather_rows(pairs, idx: torch.Tensor, M: int, V: int, dtype_code: int 
         _lib.check(rc, "dvq_prior_gather_rows")
 
 
-def prior_vrow(rows, k_blocks: int, bias, cond, label, out_packed, out_pre, M: int, N: int) -> None:
+def prior_vrow(rows, k_blocks: int, bias, cond, label, out_packed, out_pre, M: int, N: int, pre_add=None) -> None:
     """Vertical stack of one grid row.  rows: 1 or 2 entries (xs, ws) with xs = the three packed input columns of
     that input row and ws = the packed tap weights for column offsets -1, 0, +1; out_packed / out_pre: three
-    packed outputs each (out_pre entries may be None)."""
+    packed outputs each (out_pre entries may be None).  pre_add: optionally three [classes, N] tables, one per cell,
+    added by label before the gate (and to out_pre)."""
     v = DvqPriorVRow()
     v.n_rows, v.k_blocks = len(rows), k_blocks
     keep = []
@@ -510,6 +512,8 @@ def prior_vrow(rows, k_blocks: int, bias, cond, label, out_packed, out_pre, M: i
             v.x[r][c], v.w[r][c] = xs[c].data_ptr(), ws[c].data_ptr()
             keep += [xs[c], ws[c]]
     v.bias, v.cond, v.label = bias.data_ptr(), cond.data_ptr(), label.data_ptr()
+    for j in range(3):
+        v.pre_add[j] = pre_add[j].data_ptr() if pre_add is not None else None
     for j in range(3):
         v.out_packed[j] = out_packed[j].data_ptr()
         v.out_pre[j] = out_pre[j].data_ptr() if out_pre[j] is not None else None

@@ -119,6 +119,7 @@ class GatedPixelCNN(nn.Module):
         self._packed_key = None
         self._packed = None
         self._bufs = {}
+        self.class_row1 = True                 # grid row 1: the taps on grid row 0 per class as well
         self._cls = None                       # per-class constants of the weights (see _class_rows)
         self.use_graph = True                  # replay generate() as a captured HIP graph
         self.split = 1                         # sub-batches evaluated side by side (own streams and graphs)
@@ -267,7 +268,7 @@ class GatedPixelCNN(nn.Module):
 
     def _plan(self, B):
         """What a recorded graph of batch size B depends on besides the weights."""
-        return (self._n_parts(B), self.vrow_min_rows, self.class_rows, self.class_rows_min_rows)
+        return (self._n_parts(B), self.vrow_min_rows, self.class_rows, self.class_rows_min_rows, self.class_row1)
 
     def _n_parts(self, B):
         return self.split if (self.split > 1 and B >= self.split_min_rows) else 1
@@ -275,8 +276,10 @@ class GatedPixelCNN(nn.Module):
     def _gemm(self, jobs, M, N, epi, relu=False):
         ops.prior_gemm(jobs, M, N, epi, relu, self.embedding.weight, self._packed_key[1])
 
-    def _vertical_row(self, bufs, i, M, shape, label, use_vrow):
-        """Vertical stack of grid row i for all its cells: XV[l+1][i][:] and the pre-gate features HV[l][:]."""
+    def _vertical_row(self, bufs, i, M, shape, label, use_vrow, above_by_class=None):
+        """Vertical stack of grid row i for all its cells: XV[l+1][i][:] and the pre-gate features HV[l][:].
+        above_by_class: per layer None or, per cell, a [classes, 2d] table holding the taps on the row above (grid row 1,
+        whose upper row is grid row 0: per class); those taps are dropped and the table's row is added before the gate."""
         H, W = shape
         layers = self._packed[0]
         code = self._packed_key[1]
@@ -284,29 +287,32 @@ class GatedPixelCNN(nn.Module):
         d = self.dim
         kb = d // 32
         for l, t in enumerate(layers):
+            folded = above_by_class[l] if above_by_class is not None else None
+            above = (0,) if folded is not None else (-1, 0)
             if code == DVQ_BF16 and W == 3 and t.kernel == 3 and not t.mask_a and use_vrow:
                 # all three cells of the row in one launch: every input column and every tap is fetched once
                 # (smaller batches are latency-bound: per-cell launches)
                 rows = [([XV[l][i + da][c] for c in range(3)], [t.vert[(da, db)] for db in (-1, 0, 1)])
-                        for da in (-1, 0) if i + da >= 0]
+                        for da in above if i + da >= 0]
                 ops.prior_vrow(rows, kb, t.vert_bias, t.cond, label, [XV[l + 1][i][j] for j in range(3)],
-                               [HV[l][j] for j in range(3)], M, 2 * d)
+                               [HV[l][j] for j in range(3)], M, 2 * d, pre_add=folded)
                 continue
             jobs = []
             for j in range(W):
                 taps = [(XV[l][i + da][j + db], w, kb) for (da, db), w in t.vert.items()
-                        if 0 <= i + da < H and 0 <= j + db < W and (l > 0 or i + da < i)]
+                        if (folded is None or da == 0) and 0 <= i + da < H and 0 <= j + db < W and (l > 0 or i + da < i)]
                 if not taps:                                     # nothing above this row: bias only
                     taps = [(Z, next(iter(t.vert.values())), kb)]
                 jobs.append(ops.prior_job(taps, t.vert_bias, cond=t.cond, label=label, out_packed=XV[l + 1][i][j],
-                                          out_pre=HV[l][j]))
+                                          out_pre=HV[l][j], pre_add=None if folded is None else folded[j]))
             self._gemm(jobs, M, 2 * d, ops.PRIOR_GATE)
 
-    def _horizontal_cell(self, bufs, i, j, M, label, cond_with_v2h=None):
+    def _horizontal_cell(self, bufs, i, j, M, label, cond_tables=None, v2h_tap=True):
         """Horizontal stack and output head of cell (i, j): two launches per layer (taps + projected vertical
         features + gate; residual 1x1), two for the head; leaves the cell's logits in bufs["logits"].
-        cond_with_v2h: per layer a [classes, 2d] table that already holds class embedding + projected vertical
-        features (grid row 0, where the vertical features depend on the class alone): the projection tap is dropped."""
+        cond_tables: per layer a [classes, 2d] table used instead of the class embedding -- it already holds class
+        embedding + projected vertical features (grid row 0, where the vertical features depend on the class alone);
+        the projection tap is then dropped (v2h_tap=False)."""
         layers, (wo1, bo1, wo2, bo2) = self._packed
         XV, HV, XHb, OUT, HID, logits = (bufs[k] for k in ("XV", "HV", "XH", "OUT", "HID", "logits"))
         L, d = len(layers), self.dim
@@ -324,10 +330,10 @@ class GatedPixelCNN(nn.Module):
                     taps.append((XH[l], w, kb))
                 elif c == j - 1:
                     taps.append((XHp[l], w, kb))
-            if cond_with_v2h is None:
+            if v2h_tap:
                 taps.append((HV[l][j], t.v2h, 2 * kb))
-            self._gemm([ops.prior_job(taps, t.horiz_bias, cond=t.cond if cond_with_v2h is None else cond_with_v2h[l], label=label,
-                                      out_packed=OUT)], M, 2 * d, ops.PRIOR_GATE)
+            table = cond_tables[l] if cond_tables is not None and cond_tables[l] is not None else t.cond
+            self._gemm([ops.prior_job(taps, t.horiz_bias, cond=table, label=label, out_packed=OUT)], M, 2 * d, ops.PRIOR_GATE)
             self._gemm([ops.prior_job([(OUT, t.resid, kb)], t.resid_bias, resid=XH[l] if t.residual else None,
                                       out_packed=XH[l + 1])], M, d, ops.PRIOR_PACK)
         self._gemm([ops.prior_job([(XH[L], wo1, kb)], bo1, out_packed=HID)], M, bo1.numel(), ops.PRIOR_PACK, True)
@@ -370,6 +376,23 @@ class GatedPixelCNN(nn.Module):
                     self._gemm([ops.prior_job([(cls["HV"][l][j], t.v2h, 2 * d // 32)], zero, out_rows=proj)], V, 2 * d, ops.PRIOR_ROWS)
                     tabs.append((t.cond + proj).contiguous())
                 cls["cond_v2h"][j] = tabs
+            # grid row 1: from layer 1 on, its vertical stack reads grid row 0 (the taps one row up) only through
+            # activations that are per class -- evaluated per class and added before the gate by label
+            cls["above_row1"] = None
+            if shape[0] > 1:
+                rows1 = []
+                for l, t in enumerate(layers):
+                    if l == 0 or t.mask_a or not all((-1, db) in t.vert for db in (-1, 0, 1)):
+                        rows1.append(None)
+                        continue
+                    tabs = []
+                    for j in range(shape[1]):
+                        taps = [(cls["XV"][l][0][j + db], t.vert[(-1, db)], d // 32) for db in (-1, 0, 1) if 0 <= j + db < shape[1]]
+                        proj = torch.empty(V, 2 * d, dtype=torch.float32, device=dev)
+                        self._gemm([ops.prior_job(taps, zero, out_rows=proj)], V, 2 * d, ops.PRIOR_ROWS)
+                        tabs.append(proj)
+                    rows1.append(tabs)
+                cls["above_row1"] = rows1
             self._cls[key] = cls
         return self._cls[key]
 
@@ -379,9 +402,12 @@ class GatedPixelCNN(nn.Module):
         L, d = len(layers), self.dim
         cls = self._class_rows(shape, use_vrow)
         V = cls["label"].shape[0]
-        pairs = [(cls["XV"][l][0][j], bufs["XV"][l][0][j], d) for l in range(1, L) for j in range(W)]       # read by row 1
+        rows1 = cls["above_row1"]
+        pairs = [(cls["XV"][l][0][j], bufs["XV"][l][0][j], d) for l in range(1, L) for j in range(W)
+                 if H > 1 and (rows1 is None or rows1[l] is None or not self.class_row1)]   # read by row 1 where its taps are not folded
         pairs += [(cls["XH"][0][l], bufs["XH"][0][l], d) for l in range(1, L)]                              # cell (0, 1)
-        ops.prior_gather_rows(pairs, label, B, V, self._packed_key[1])
+        if pairs:
+            ops.prior_gather_rows(pairs, label, B, V, self._packed_key[1])
         ops.vq_gather(label, cls["logits"], out=bufs["logits"])
 
     def _run_hip(self, bufs, shape, B, generator, return_probs, uniforms, x_out=None):
@@ -401,11 +427,15 @@ class GatedPixelCNN(nn.Module):
             if i == 0 and by_class:
                 self._first_row_by_class(bufs, B, shape, label, use_vrow)
             else:
-                self._vertical_row(bufs, i, B, shape, label, use_vrow)
+                above = self._class_rows(shape, use_vrow)["above_row1"] if (i == 1 and by_class and self.class_row1) else None
+                self._vertical_row(bufs, i, B, shape, label, use_vrow, above)
             for j in range(W):
                 if not (i == 0 and j == 0 and by_class):
-                    table = self._class_rows(shape, use_vrow)["cond_v2h"][j] if (i == 0 and by_class) else None
-                    self._horizontal_cell(bufs, i, j, B, label, table)
+                    cls = self._class_rows(shape, use_vrow) if by_class else None
+                    if by_class and i == 0:
+                        self._horizontal_cell(bufs, i, j, B, label, cls["cond_v2h"][j], v2h_tap=False)
+                    else:
+                        self._horizontal_cell(bufs, i, j, B, label)
                 if uniforms is not None and not return_probs:
                     # softmax, draw, grid write and embedding of the drawn code in one launch
                     ops.prior_sample(logits, uniforms[:, i * W + j], x[:, i, j], emb, XV[0][i][j], code)

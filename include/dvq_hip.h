@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 110   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 111   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -277,6 +277,7 @@ typedef struct {
     void* out_packed;
     void* out_pre;
     float* out_rows;
+    const float* pre_add;   /* GATE, optional: [n_classes, N] added to y by label BEFORE the gate (part of out_pre too) */
 } DvqPriorJob;
 
 size_t dvq_prior_packed_bytes(int rows, int features, int dtype);
@@ -311,6 +312,7 @@ typedef struct {
     const int64_t* label;    /* [M]            */
     void* out_packed[3];
     void* out_pre[3];
+    const float* pre_add[3]; /* optional, per cell: [n_classes, N] added to y_j by label before the gate (part of out_pre) */
 } DvqPriorVRow;
 int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream);
 

@@ -131,22 +131,24 @@ def test_prior_bf16_kernels_vs_fp32():
 def test_prior_rows_by_class_equal_rows_evaluated_one_by_one(dtype):
     """Grid row 0's vertical stack and cell (0, 0) see nothing but the class label; generate() evaluates them once per
     class and hands the rows out (dvq_prior_gather_rows).  Same kernels, same numbers: cell (0, 0)'s distribution is
-    bit-equal to evaluating every row.  In cells (0, 1..) the projected vertical features reach the gate through the
-    per-class table instead of the accumulator (another fp32 summation order): the distributions agree to rounding
-    wherever the grids drawn so far agree, and nearly all grids agree.  At a ragged batch and at one grid."""
+    bit-equal to evaluating every row.  In cells (0, 1..) the projected vertical features, and in grid row 1 the taps
+    on grid row 0 (class_row1), reach the gate through per-class tables instead of the accumulator (another fp32
+    summation order): the distributions agree to rounding wherever the grids drawn so far agree, and nearly all grids
+    agree.  At a ragged batch and at one grid."""
     from dvq_hip import ops, rng
     model, _ = build()
     prior = model.GatedPixelCNN
     prior.compute_dtype = dtype
     tol = 1e-5 if dtype == torch.float32 else 5e-3
-    for B in (301, 1):
+    for B, row1 in ((301, True), (301, False), (1, True)):
         lab = torch.randint(0, 128, (B,), device=DEV, generator=torch.Generator(DEV).manual_seed(4))
         u = rng.uniforms(torch.arange(B, device=DEV), 9, seed=11)
         out = {}
+        prior.class_row1 = row1
         for on in (True, False):
             prior.class_rows = on
             out[on] = prior.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u, return_probs=True)
-        prior.class_rows = True
+        prior.class_rows = prior.class_row1 = True
         (xa, pa), (xb, pb) = out[True], out[False]
         assert torch.equal(pa[:, 0], pb[:, 0])   # (both batch sizes take the kernel the 128 class rows take)
         same = torch.ones(B, dtype=torch.bool, device=DEV)       # grids equal in every cell drawn before this one
@@ -154,8 +156,11 @@ def test_prior_rows_by_class_equal_rows_evaluated_one_by_one(dtype):
             if bool(same.any()):
                 assert (pa[same, c] - pb[same, c]).abs().max().item() <= tol, c
             same &= xa.reshape(B, 9)[:, c] == xb.reshape(B, 9)[:, c]
-        # (bf16: a product rounded the other way moves a draw that sat on a boundary, a few grids in a thousand)
-        assert same.float().mean().item() >= (1.0 if B == 1 else 0.99 if dtype == torch.float32 else 0.97)
+        # bf16: a feature rounded the other way moves a draw that sat on a boundary -- a few grids in a hundred with
+        # the 42 vertical products of grid row 1 summed in the other order (two bf16 evaluations of the same model
+        # agree on 94 %; bf16 against fp32: 95 %, test_prior_bf16_kernels_vs_fp32), a few in a thousand without
+        floor = 1.0 if B == 1 else 0.99 if dtype == torch.float32 else (0.90 if row1 else 0.97)
+        assert same.float().mean().item() >= floor
     # the gather itself: packed rows of a table handed out by index, against prior_embed of the same rows
     code = ops.DVQ_BF16 if dtype == torch.bfloat16 else ops.DVQ_F32
     V, M, d = 50, 77, 96
