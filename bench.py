@@ -166,7 +166,7 @@ def prior_roofline(gen, B, device, iters=20):
             "traffic": None, "avg_launch_ms": round(ms, 5), "launches_timed": iters, "l2_to_lds_bytes_per_launch": l2_bytes,
             "tflops": round(flops / ms / 1e9, 1), "frac_mfma_peak": round(flops / ms / 1e9 / PEAK_TFLOPS["bf16"], 4),
             "note": "launched back to back outside the replayed graph (independent launches: no dependent-chain stalls); "
-                    "120 such launches (30 of them, in grid row 0, with one tap less) + 120 residual 1x1 products + 30 "
+                    "120 such launches (30 of them, in grid row 0, with one or two taps less) + 120 residual 1x1 products + 30 "
                     "vertical-row launches make one grid batch (grid row 0's vertical stack and cell (0,0) are "
                     "per-class constants of the weights)"}
 
@@ -337,10 +337,10 @@ def main():
                                    (f" + {'RCCL' if args.backend == 'nccl' else args.backend} all-gather of vertices" if world > 1 else ""),
                        "objects_per_gpu": B, "points_per_object": N, "global_batch": world * B,
                        "prior": args.prior,
-                       "prior_note": "every grid is sampled in full each step; what the sampler computes before its first draw "
-                                     "(vertical stack of grid row 0, cell (0,0)) depends on the class label alone and is a table "
-                                     "of 128 rows computed from the weights, like the packed weights -- no step's inputs or "
-                                     "outputs are cached",
+                       "prior_note": "every grid is sampled in full each step; what depends on the class label alone (the "
+                                     "vertical stack of grid row 0, cell (0,0), and the terms of cells (0,1..) and of grid row 1's "
+                                     "vertical stack that read only those) is tabulated per class (128 rows) from the weights, like "
+                                     "the packed weights -- no step's inputs or outputs are cached",
                        "tta_iterations": args.tta_iters, "weights": "random-init (seed 0), MANO-shaped synthetic hand model",
                        "parallelism": f"dp{world}"},
         }

@@ -307,12 +307,13 @@ class GatedPixelCNN(nn.Module):
                                           out_pre=HV[l][j], pre_add=None if folded is None else folded[j]))
             self._gemm(jobs, M, 2 * d, ops.PRIOR_GATE)
 
-    def _horizontal_cell(self, bufs, i, j, M, label, cond_tables=None, v2h_tap=True):
+    def _horizontal_cell(self, bufs, i, j, M, label, cond_tables=None, v2h_tap=True, prev_tap=True):
         """Horizontal stack and output head of cell (i, j): two launches per layer (taps + projected vertical
         features + gate; residual 1x1), two for the head; leaves the cell's logits in bufs["logits"].
         cond_tables: per layer a [classes, 2d] table used instead of the class embedding -- it already holds class
         embedding + projected vertical features (grid row 0, where the vertical features depend on the class alone);
-        the projection tap is then dropped (v2h_tap=False)."""
+        the projection tap is then dropped (v2h_tap=False).  prev_tap=False: the table also holds the taps on the
+        cell to the left from layer 1 on (cell (0, 1), whose left neighbour (0, 0) is per class), which are dropped."""
         layers, (wo1, bo1, wo2, bo2) = self._packed
         XV, HV, XHb, OUT, HID, logits = (bufs[k] for k in ("XV", "HV", "XH", "OUT", "HID", "logits"))
         L, d = len(layers), self.dim
@@ -328,7 +329,7 @@ class GatedPixelCNN(nn.Module):
                     taps.append((XV[0][i][c], w, kb))
                 elif c == j:
                     taps.append((XH[l], w, kb))
-                elif c == j - 1:
+                elif c == j - 1 and prev_tap:
                     taps.append((XHp[l], w, kb))
             if v2h_tap:
                 taps.append((HV[l][j], t.v2h, 2 * kb))
@@ -346,7 +347,9 @@ class GatedPixelCNN(nn.Module):
     # (_first_row_by_class) -- equal to evaluating every row (to the bit when the batch takes the same product
     # kernel as the 128 class rows, to fp32 rounding otherwise).  The rest of grid row 0 reads the row's vertical
     # features only through their 1x1 projection into the gate: that projection, per class as well, is added to the
-    # class-embedding table those cells' gate epilogue looks up, so the tap and the copies of the features go.
+    # class-embedding table those cells' gate epilogue looks up, so the tap and the copies of the features go; so do
+    # cell (0, 1)'s taps on cell (0, 0) and, in grid row 1, the vertical taps on grid row 0 (added before the gate by
+    # label): what the batch is handed by label in the end is cell (0, 0)'s logits and nothing else.
     def _by_class(self, B):
         return self.class_rows and B >= self.class_rows_min_rows
 
@@ -373,7 +376,10 @@ class GatedPixelCNN(nn.Module):
                 tabs = []
                 for l, t in enumerate(layers):
                     proj = torch.empty(V, 2 * d, dtype=torch.float32, device=dev)
-                    self._gemm([ops.prior_job([(cls["HV"][l][j], t.v2h, 2 * d // 32)], zero, out_rows=proj)], V, 2 * d, ops.PRIOR_ROWS)
+                    taps = [(cls["HV"][l][j], t.v2h, 2 * d // 32)]
+                    if j == 1 and l > 0 and -1 in t.horiz:
+                        taps.append((cls["XH"][0][l], t.horiz[-1], d // 32))     # cell (0, 0)'s features, per class too
+                    self._gemm([ops.prior_job(taps, zero, out_rows=proj)], V, 2 * d, ops.PRIOR_ROWS)
                     tabs.append((t.cond + proj).contiguous())
                 cls["cond_v2h"][j] = tabs
             # grid row 1: from layer 1 on, its vertical stack reads grid row 0 (the taps one row up) only through
@@ -405,7 +411,6 @@ class GatedPixelCNN(nn.Module):
         rows1 = cls["above_row1"]
         pairs = [(cls["XV"][l][0][j], bufs["XV"][l][0][j], d) for l in range(1, L) for j in range(W)
                  if H > 1 and (rows1 is None or rows1[l] is None or not self.class_row1)]   # read by row 1 where its taps are not folded
-        pairs += [(cls["XH"][0][l], bufs["XH"][0][l], d) for l in range(1, L)]                              # cell (0, 1)
         if pairs:
             ops.prior_gather_rows(pairs, label, B, V, self._packed_key[1])
         ops.vq_gather(label, cls["logits"], out=bufs["logits"])
@@ -433,7 +438,7 @@ class GatedPixelCNN(nn.Module):
                 if not (i == 0 and j == 0 and by_class):
                     cls = self._class_rows(shape, use_vrow) if by_class else None
                     if by_class and i == 0:
-                        self._horizontal_cell(bufs, i, j, B, label, cls["cond_v2h"][j], v2h_tap=False)
+                        self._horizontal_cell(bufs, i, j, B, label, cls["cond_v2h"][j], v2h_tap=False, prev_tap=j != 1)
                     else:
                         self._horizontal_cell(bufs, i, j, B, label)
                 if uniforms is not None and not return_probs:
