@@ -203,11 +203,14 @@ def test_prior_vrow_kernel_equals_three_per_cell_products():
         ws = [[ops.prior_pack_weight(torch.randn(N, d, device=DEV, generator=g) * 0.05) for _ in range(3)] for _ in range(n_rows)]
         outs = [[ops.prior_packed_empty(M, N // 2, DEV, True) for _ in range(3)] for _ in range(2)]
         pres = [[ops.prior_packed_empty(M, N, DEV, True) for _ in range(3)] for _ in range(2)]
-        ops.prior_vrow([(xs[r], ws[r]) for r in range(n_rows)], d // 32, bias, cond, label, outs[0], pres[0], M, N)
+        # (with and without the optional per-class addend that goes in before the gate)
+        add = [torch.randn(n_cls, N, device=DEV, generator=g) * 0.1 for _ in range(3)] if M == 4096 else None
+        ops.prior_vrow([(xs[r], ws[r]) for r in range(n_rows)], d // 32, bias, cond, label, outs[0], pres[0], M, N, pre_add=add)
         jobs = []
         for j in range(3):
             taps = [(xs[r][c], ws[r][c - j + 1], d // 32) for r in range(n_rows) for c in range(3) if abs(c - j) <= 1]
-            jobs.append(ops.prior_job(taps, bias, cond=cond, label=label, out_packed=outs[1][j], out_pre=pres[1][j]))
+            jobs.append(ops.prior_job(taps, bias, cond=cond, label=label, out_packed=outs[1][j], out_pre=pres[1][j],
+                                      pre_add=None if add is None else add[j]))
         ops.prior_gemm(jobs, M, N, ops.PRIOR_GATE, False, bias)
         for a, b in zip(outs[0] + pres[0], outs[1] + pres[1]):
             fa = a.view(torch.bfloat16).float()
@@ -215,6 +218,16 @@ def test_prior_vrow_kernel_equals_three_per_cell_products():
             assert torch.isfinite(fa).all()
             assert (fa - fb).abs().max().item() <= 2.0 ** -7 * fb.abs().max().item()
             assert (fa != fb).float().mean().item() < 0.05
+        if add is not None:    # the addend is part of the pre-gate output: pre(with) - pre(without) = add[label]
+            pres0 = [ops.prior_packed_empty(M, N, DEV, True) for _ in range(3)]
+            ops.prior_vrow([(xs[r], ws[r]) for r in range(n_rows)], d // 32, bias, cond, label,
+                           [ops.prior_packed_empty(M, N // 2, DEV, True) for _ in range(3)], pres0, M, N)
+            rows_of = lambda packed: packed.view(torch.bfloat16).float().view(N // 32, (M + 31) // 32, 2, 32, 2, 2, 4)
+            for j in range(3):     # unit (fb, sb, s): lane (c, h), e -> feature 32 fb + 16 s + 8 (e >> 2) + 4 h + (e & 3)
+                diff = rows_of(pres[0][j]) - rows_of(pres0[j])                       # [fb, sb, s, h, c, e2, e4] as stored
+                diff = diff.view(N // 32, (M + 31) // 32, 2, 2, 32, 2, 4)             # [fb, sb, s, h, c, e>>2, e&3]
+                feat = diff.permute(1, 4, 0, 2, 5, 3, 6).reshape(-1, N)[:M]          # [sample, fb, s, e>>2, h, e&3]
+                assert (feat - add[j][label]).abs().max().item() <= 2.0 ** -7 * rows_of(pres0[j]).abs().max().item()   # two bf16 roundings
 
 
 @pytest.mark.gpu
