@@ -26,14 +26,18 @@ constexpr int kMH = 16;       // hands per workgroup
 constexpr int kJ = 16;        // joints
 constexpr int kPF = 135;      // pose-feature length = 15 joints * 9
 constexpr int kKS = 34;       // MFMA k-steps of 4 over the pose features (135 + one zero)
-constexpr int kManoThreads = 256;    // phase A uses all of them (hand x joint), phase B the first 48, phase C four waves
+constexpr int kManoThreads = 256;    // dense form: phase A uses all of them (hand x joint), phase B the first 48, phase C four waves
 constexpr int kSkinW = 8;     // slots per vertex in the skinning table
 
 struct f32x3 { float x, y, z; };
 
 // TABLE: skinning weights come as kSkinW (joint, weight) slots per vertex; otherwise as the dense [V,16] matrix.
-template <bool TABLE>
-__global__ __launch_bounds__(kManoThreads) void mano_lbs_kernel(
+// WAVES = 8 (table form): two waves per SIMD, one's skinning under the other's MFMAs; the group's operand then comes in
+// six chunks of six k-steps through two register buffers (102 registers for all of it would not leave room for two
+// waves; chunks of nine leave the kernel a few registers short, and a spilled register here costs more than the chunking gains)
+// and the pose features are read from LDS at each step instead of living in 34 registers.
+template <bool TABLE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     const float* __restrict__ global_orient, const float* __restrict__ hand_pose, const float* __restrict__ transl,
     int B, int V, int ncomp, const float* __restrict__ v_shaped, const float* __restrict__ joints,
     const float* __restrict__ posedirs, const float* __restrict__ weights, const float* __restrict__ comps,
@@ -53,14 +57,15 @@ __global__ __launch_bounds__(kManoThreads) void mano_lbs_kernel(
     __shared__ float sJ[kJ * 3];         // rest joints
     __shared__ int sPar[kJ];
 
+    constexpr int THREADS = WAVES * 64;
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * kMH;
     const int nh = (B - b0) < kMH ? (B - b0) : kMH;
 
     // Everything the two serial phases read goes to LDS in one round of coalesced loads: fetched where it is used
     // (45 dependent steps of the PCA product, 16 of the chain) each load would cost a trip to L2.
-    for (int i = tid; i < nh * ncomp; i += kManoThreads) sHP[i / ncomp][i % ncomp] = hand_pose[(int64_t)b0 * ncomp + i];
-    for (int i = tid; i < ncomp * 45; i += kManoThreads) sComps[i] = comps[i];
+    for (int i = tid; i < nh * ncomp; i += THREADS) sHP[i / ncomp][i % ncomp] = hand_pose[(int64_t)b0 * ncomp + i];
+    for (int i = tid; i < ncomp * 45; i += THREADS) sComps[i] = comps[i];
     if (tid < kJ * 3) sJ[tid] = joints[tid];
     if (tid < kJ) sPar[tid] = parents[tid];
     __syncthreads();
@@ -161,16 +166,22 @@ __global__ __launch_bounds__(kManoThreads) void mano_lbs_kernel(
     // ---- C: per group of 16 vertices: pose blend shapes on the matrix cores, then skinning   (lbs.py:90-118)
     const int lane = tid & 63, wave = tid >> 6;
     const int h = lane & 15, q = lane >> 4;
-    float bfrag[kKS];                                   // B operand: pose feature 4s + q of hand h
+    constexpr bool CHUNKED = WAVES == 8;
+    float bfrag[CHUNKED ? 1 : kKS];                     // B operand: pose feature 4s + q of hand h
+    if (!CHUNKED) {
 #pragma unroll
-    for (int s = 0; s < kKS; ++s) bfrag[s] = sPF[h][4 * s + q];
+        for (int s = 0; s < kKS; ++s) bfrag[s] = sPF[h][4 * s + q];
+    }
     const int n_groups = (V + 15) / 16;
     const int64_t prow = 3 * (int64_t)V;
     // A operand of group g: vertex 16g + (lane & 15), pose feature 4s + q; tile t = coordinate axis t.  All 34 k-steps
     // of a group are fetched at once (12 B per lane each) and the next group's are requested before this group's
     // skinning, so the L2 latency is paid under vector work.  Feature 135 does not exist: its B operand is zero, the
     // load is clamped to feature 134; vertices past the end are clamped too and never stored.
-    f32x3 afrag[kKS];
+    constexpr int CH = 6, NCH = (kKS + CH - 1) / CH;     // chunked form: k-steps per chunk, chunks per group
+    static_assert(NCH % 2 == 0, "the last chunk must use the second buffer: the next group's first chunk is loaded into the first meanwhile");
+    f32x3 afrag[CHUNKED ? 1 : kKS];
+    f32x3 abuf[2][CHUNKED ? CH : 1];
     auto load_group = [&](int g) {
         int vr = 16 * g + h;
         if (vr >= V) vr = V - 1;
@@ -178,7 +189,20 @@ __global__ __launch_bounds__(kManoThreads) void mano_lbs_kernel(
 #pragma unroll
         for (int s = 0; s < kKS; ++s) {
             const int k = (4 * s + q) < kPF ? (4 * s + q) : kPF - 1;
-            afrag[s] = *reinterpret_cast<const f32x3*>(pd + k * prow);
+            afrag[CHUNKED ? 0 : s] = *reinterpret_cast<const f32x3*>(pd + k * prow);
+        }
+    };
+    auto load_chunk = [&](int g, int ci, f32x3* dst) {
+        int vr = 16 * g + h;
+        if (vr >= V) vr = V - 1;
+        const float* pd = posedirs + 3 * (int64_t)vr;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int ks = ci * CH + s;
+            if (ks < kKS) {
+                const int k = (4 * ks + q) < kPF ? (4 * ks + q) : kPF - 1;
+                dst[s] = *reinterpret_cast<const f32x3*>(pd + k * prow);
+            }
         }
     };
     // the skinning slots of this lane's four vertices, requested before the group's MFMAs and used after them
@@ -198,21 +222,43 @@ __global__ __launch_bounds__(kManoThreads) void mano_lbs_kernel(
             vs[i] = *reinterpret_cast<const f32x3*>(v_shaped + (int64_t)v * 3);
         }
     };
-    if (wave < n_groups) load_group(wave);
-    for (int g = wave; g < n_groups; g += kManoThreads / 64) {
+    if (wave < n_groups) {
+        if (CHUNKED) load_chunk(wave, 0, abuf[0]);
+        else load_group(wave);
+    }
+    for (int g = wave; g < n_groups; g += WAVES) {
         const int v0 = 16 * g;
         if (TABLE) load_skin(g);
         f32x4 acc[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (CHUNKED) {
 #pragma unroll
-        for (int s = 0; s < kKS; ++s) {
-            const float bf = bfrag[s];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].x, bf, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].y, bf, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].z, bf, acc[2], 0, 0, 0);
+            for (int ci = 0; ci < NCH; ++ci) {
+                // the next chunk (or the next group's first) is requested into the other buffer before this one is used
+                if (ci + 1 < NCH) load_chunk(g, ci + 1, abuf[(ci + 1) & 1]);
+                else if (g + WAVES < n_groups) load_chunk(g + WAVES, 0, abuf[0]);
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    const int ks = ci * CH + s;
+                    if (ks < kKS) {
+                        const float bf = sPF[h][4 * ks + q];
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[ci & 1][s].x, bf, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[ci & 1][s].y, bf, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[ci & 1][s].z, bf, acc[2], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < kKS; ++s) {
+                const float bf = bfrag[s];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].x, bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].y, bf, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s].z, bf, acc[2], 0, 0, 0);
+            }
+            if (g + WAVES < n_groups) load_group(g + WAVES);
         }
-        if (g + kManoThreads / 64 < n_groups) load_group(g + kManoThreads / 64);
         if (!TABLE) load_skin(g);
         // this lane: hand h, vertices v0 + 4q + i (register i of the three tiles)
         const int64_t hb = (int64_t)(b0 + (h < nh ? h : 0)) * V;
@@ -228,29 +274,44 @@ __global__ __launch_bounds__(kManoThreads) void mano_lbs_kernel(
             }
         }
         if (h >= nh) continue;
+        // T_i = sum_j w_j A_j over the slots (joints ascending), VP of the lane's four vertices side by side: the LDS reads
+        // of a slot step (3 per vertex) are in flight together, where one vertex at a time waits out the LDS latency per slot.
+        constexpr int VP = TABLE ? 2 : 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = v0 + 4 * q + i;
-            if (v >= V) break;
-            // T = sum_j w_j A_j over the slots (joints ascending)
-            float T[12];
+        for (int i0 = 0; i0 < 4; i0 += VP) {
+        float T[VP][12];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int u = 0; u < VP; ++u)
 #pragma unroll
-            for (int e = 0; e < NSLOT; ++e) {
-                if (e >= n_slots) break;
+            for (int e = 0; e < 12; ++e) T[u][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < NSLOT; ++e) {
+            if (e >= n_slots) break;
+            f32x4 A0[VP], A1[VP], A2[VP];
+#pragma unroll
+            for (int u = 0; u < VP; ++u) {
+                const int i = i0 + u;
                 const int j = TABLE ? (int)(((e < 4 ? sj[i].x : sj[i].y) >> (8 * (e & 3))) & 15u) : e;
-                const float w = sw[i][e / 4][e % 4];
-                const f32x4 A0 = *reinterpret_cast<const f32x4*>(sA(h, j));
-                const f32x4 A1 = *reinterpret_cast<const f32x4*>(sA(h, j) + 4);
-                const f32x4 A2 = *reinterpret_cast<const f32x4*>(sA(h, j) + 8);
+                A0[u] = *reinterpret_cast<const f32x4*>(sA(h, j));
+                A1[u] = *reinterpret_cast<const f32x4*>(sA(h, j) + 4);
+                A2[u] = *reinterpret_cast<const f32x4*>(sA(h, j) + 8);
+            }
+#pragma unroll
+            for (int u = 0; u < VP; ++u) {
+                const float w = sw[i0 + u][e / 4][e % 4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    T[c] = __builtin_fmaf(w, A0[c], T[c]);
-                    T[4 + c] = __builtin_fmaf(w, A1[c], T[4 + c]);
-                    T[8 + c] = __builtin_fmaf(w, A2[c], T[8 + c]);
+                    T[u][c] = __builtin_fmaf(w, A0[u][c], T[u][c]);
+                    T[u][4 + c] = __builtin_fmaf(w, A1[u][c], T[u][4 + c]);
+                    T[u][8 + c] = __builtin_fmaf(w, A2[u][c], T[u][8 + c]);
                 }
             }
+        }
+#pragma unroll
+        for (int u = 0; u < VP; ++u) {
+            const int i = i0 + u;
+            const int v = v0 + 4 * q + i;
+            if (v >= V) break;
             // v_posed = pose_offsets + v_shaped  (lbs.py:101)
             const float px = acc[0][i] + vs[i].x, py = acc[1][i] + vs[i].y, pz = acc[2][i] + vs[i].z;
             if (v_posed_out) {   // kept for dvq_mano_lbs_backward
@@ -261,13 +322,14 @@ __global__ __launch_bounds__(kManoThreads) void mano_lbs_kernel(
             float* dst = &o.x;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                float r = T[a * 4 + 0] * px;
-                r = __builtin_fmaf(T[a * 4 + 1], py, r);
-                r = __builtin_fmaf(T[a * 4 + 2], pz, r);
-                r = r + T[a * 4 + 3];
+                float r = T[u][a * 4 + 0] * px;
+                r = __builtin_fmaf(T[u][a * 4 + 1], py, r);
+                r = __builtin_fmaf(T[u][a * 4 + 2], pz, r);
+                r = r + T[u][a * 4 + 3];
                 dst[a] = r + sTr[h][a];
             }
             *reinterpret_cast<f32x3*>(verts_out + (hb + v) * 3) = o;
+        }
         }
     }
 }
@@ -291,11 +353,11 @@ extern "C" int dvq_mano_lbs(const float* global_orient, const float* hand_pose, 
     if (((uintptr_t)m->lbs_weights & 15) != 0) return fail(DVQ_EINVAL, "mano: lbs_weights must be 16-byte aligned");
     const int grid = (B + kMH - 1) / kMH;
     if (table)
-        hipLaunchKernelGGL(mano_lbs_kernel<true>, dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
+        hipLaunchKernelGGL((mano_lbs_kernel<true, 8>), dim3(grid), dim3(512), 0, as_stream(stream), global_orient, hand_pose, transl, B,
                            m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
                            m->parents, m->skin_joints, m->skin_weights, verts_out, joints_out, full_pose_out, v_posed_out);
     else
-        hipLaunchKernelGGL(mano_lbs_kernel<false>, dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
+        hipLaunchKernelGGL((mano_lbs_kernel<false, 4>), dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
                            m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
                            m->parents, nullptr, nullptr, verts_out, joints_out, full_pose_out, v_posed_out);
     return check_launch("mano_lbs");
