@@ -30,19 +30,20 @@ constexpr int kManoThreads = 256;    // dense form: phase A uses all of them (ha
 constexpr int kSkinW = 8;     // slots per vertex in the skinning table
 
 struct f32x3 { float x, y, z; };
+typedef f32x4 f32x4u __attribute__((aligned(4)));   // four floats at any 4-byte boundary (a hand's rows start at multiples of 8 bytes)
 
 // TABLE: skinning weights come as kSkinW (joint, weight) slots per vertex; otherwise as the dense [V,16] matrix.
 // WAVES = 8 (table form): two waves per SIMD, one's skinning under the other's MFMAs; the group's operand then comes in
 // six chunks of six k-steps through two register buffers (102 registers for all of it would not leave room for two
 // waves; chunks of nine leave the kernel a few registers short, and a spilled register here costs more than the chunking gains)
 // and the pose features are read from LDS at each step instead of living in 34 registers.
-template <bool TABLE, int WAVES>
+template <bool TABLE, int WAVES, bool LANES>
 __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     const float* __restrict__ global_orient, const float* __restrict__ hand_pose, const float* __restrict__ transl,
     int B, int V, int ncomp, const float* __restrict__ v_shaped, const float* __restrict__ joints,
     const float* __restrict__ posedirs, const float* __restrict__ weights, const float* __restrict__ comps,
     const float* __restrict__ pose_mean, const int* __restrict__ parents, const unsigned char* __restrict__ skin_joints,
-    const float* __restrict__ skin_weights, float* __restrict__ verts_out,
+    const float* __restrict__ skin_weights, const float* __restrict__ pd_lanes, float* __restrict__ verts_out,
     float* __restrict__ joints_out, float* __restrict__ full_pose_out, float* __restrict__ v_posed_out) {
     __shared__ float sR[kMH][kJ][9];     // rotation matrices
     // relative transforms, upper 3x4; 4 floats of padding per hand: the skinning gather reads sA[h][j] with h = lane & 15,
@@ -56,6 +57,9 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     __shared__ float sComps[45 * 45];    // PCA basis
     __shared__ float sJ[kJ * 3];         // rest joints
     __shared__ int sPar[kJ];
+    // per wave: a group's 16 hands x 16 vertices x 3 results on their way out (row padded from 48 so that the hands'
+    // rows start on different banks); [..][0] takes the vertices, [..][1] the pre-skinning vertices
+    __shared__ __attribute__((aligned(16))) float sOut[WAVES][2][kMH][52];
 
     constexpr int THREADS = WAVES * 64;
     const int tid = threadIdx.x;
@@ -195,13 +199,13 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     auto load_chunk = [&](int g, int ci, f32x3* dst) {
         int vr = 16 * g + h;
         if (vr >= V) vr = V - 1;
-        const float* pd = posedirs + 3 * (int64_t)vr;
+        const float* pd = LANES ? pd_lanes + ((int64_t)g * kKS * 64 + lane) * 3 : posedirs + 3 * (int64_t)vr;
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             const int ks = ci * CH + s;
             if (ks < kKS) {
                 const int k = (4 * ks + q) < kPF ? (4 * ks + q) : kPF - 1;
-                dst[s] = *reinterpret_cast<const f32x3*>(pd + k * prow);
+                dst[s] = *reinterpret_cast<const f32x3*>(LANES ? pd + ks * 192 : pd + k * prow);
             }
         }
     };
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
             }
         }
         if (h >= nh) continue;
+        const bool full = v0 + 16 <= V;
         // T_i = sum_j w_j A_j over the slots (joints ascending), VP of the lane's four vertices side by side: the LDS reads
         // of a slot step (3 per vertex) are in flight together, where one vertex at a time waits out the LDS latency per slot.
         constexpr int VP = TABLE ? 2 : 1;
@@ -315,8 +320,13 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
             // v_posed = pose_offsets + v_shaped  (lbs.py:101)
             const float px = acc[0][i] + vs[i].x, py = acc[1][i] + vs[i].y, pz = acc[2][i] + vs[i].z;
             if (v_posed_out) {   // kept for dvq_mano_lbs_backward
-                f32x3 o = {px, py, pz};
-                *reinterpret_cast<f32x3*>(v_posed_out + (hb + v) * 3) = o;
+                if (full) {
+                    float* st = &sOut[wave][1][h][(4 * q + i) * 3];
+                    st[0] = px, st[1] = py, st[2] = pz;
+                } else {
+                    f32x3 o = {px, py, pz};
+                    *reinterpret_cast<f32x3*>(v_posed_out + (hb + v) * 3) = o;
+                }
             }
             f32x3 o;
             float* dst = &o.x;
@@ -328,8 +338,31 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
                 r = r + T[u][a * 4 + 3];
                 dst[a] = r + sTr[h][a];
             }
-            *reinterpret_cast<f32x3*>(verts_out + (hb + v) * 3) = o;
+            if (full) {
+                float* st = &sOut[wave][0][h][(4 * q + i) * 3];
+                st[0] = o.x, st[1] = o.y, st[2] = o.z;
+            } else {
+                *reinterpret_cast<f32x3*>(verts_out + (hb + v) * 3) = o;
+            }
         }
+        }
+        // A hand's 16 vertices of the group are 192 contiguous bytes of the output, and a lane holds 48 of them: written
+        // from the registers, each store instruction would touch every line of every hand.  Through LDS the four lanes
+        // of a hand write 64 contiguous bytes per instruction (LDS operations of one wave execute in order, and a hand's
+        // row is written and read by its own four lanes only).  The last, partial group stores from the registers.
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&sOut[wave][0][h][16 * k + 4 * q]);
+                *reinterpret_cast<f32x4u*>(verts_out + (hb + v0) * 3 + 16 * k + 4 * q) = t;
+            }
+            if (v_posed_out) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(&sOut[wave][1][h][16 * k + 4 * q]);
+                    *reinterpret_cast<f32x4u*>(v_posed_out + (hb + v0) * 3 + 16 * k + 4 * q) = t;
+                }
+            }
         }
     }
 }
@@ -351,14 +384,19 @@ extern "C" int dvq_mano_lbs(const float* global_orient, const float* hand_pose, 
     if (table && (!m->skin_weights || m->skin_width != kSkinW || ((uintptr_t)m->skin_joints & 7) || ((uintptr_t)m->skin_weights & 15)))
         return fail(DVQ_EINVAL, "mano: the skinning table needs skin_weights, skin_width == %d and aligned arrays (joints 8, weights 16 bytes)", kSkinW);
     if (((uintptr_t)m->lbs_weights & 15) != 0) return fail(DVQ_EINVAL, "mano: lbs_weights must be 16-byte aligned");
+    if (((uintptr_t)m->posedirs_lanes & 3) != 0) return fail(DVQ_EINVAL, "mano: posedirs_lanes must be 4-byte aligned");
     const int grid = (B + kMH - 1) / kMH;
-    if (table)
-        hipLaunchKernelGGL((mano_lbs_kernel<true, 8>), dim3(grid), dim3(512), 0, as_stream(stream), global_orient, hand_pose, transl, B,
+    if (table && m->posedirs_lanes)
+        hipLaunchKernelGGL((mano_lbs_kernel<true, 8, true>), dim3(grid), dim3(512), 0, as_stream(stream), global_orient, hand_pose, transl, B,
                            m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
-                           m->parents, m->skin_joints, m->skin_weights, verts_out, joints_out, full_pose_out, v_posed_out);
+                           m->parents, m->skin_joints, m->skin_weights, m->posedirs_lanes, verts_out, joints_out, full_pose_out, v_posed_out);
+    else if (table)
+        hipLaunchKernelGGL((mano_lbs_kernel<true, 8, false>), dim3(grid), dim3(512), 0, as_stream(stream), global_orient, hand_pose, transl, B,
+                           m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
+                           m->parents, m->skin_joints, m->skin_weights, nullptr, verts_out, joints_out, full_pose_out, v_posed_out);
     else
-        hipLaunchKernelGGL((mano_lbs_kernel<false, 4>), dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
+        hipLaunchKernelGGL((mano_lbs_kernel<false, 4, false>), dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
                            m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
-                           m->parents, nullptr, nullptr, verts_out, joints_out, full_pose_out, v_posed_out);
+                           m->parents, nullptr, nullptr, nullptr, verts_out, joints_out, full_pose_out, v_posed_out);
     return check_launch("mano_lbs");
 }

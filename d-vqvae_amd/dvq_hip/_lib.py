@@ -31,7 +31,7 @@ class DvqManoConsts(ctypes.Structure):
     _fields_ = [("n_verts", c_int), ("n_comps", c_int), ("v_shaped", c_void_p), ("joints", c_void_p),
                 ("posedirs", c_void_p), ("lbs_weights", c_void_p), ("components", c_void_p),
                 ("pose_mean", c_void_p), ("parents", c_void_p), ("skin_joints", c_void_p), ("skin_weights", c_void_p),
-                ("skin_width", c_int)]
+                ("skin_width", c_int), ("posedirs_lanes", c_void_p)]
 
 
 class DvqHandMesh(ctypes.Structure):

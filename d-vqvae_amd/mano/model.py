@@ -180,7 +180,13 @@ class MANO(nn.Module):
                 width = 8                                 # slots of the kernel's table; denser models take the dense path
                 has_table = int(nz.sum(1).max()) <= width
                 order = torch.argsort((~nz).to(torch.int8), dim=1, stable=True)[:, :width]
-                keep = dict(v_shaped=v_shaped.contiguous(), joints=joints.contiguous(),
+                # posedirs once more in the order the kernel's lanes read it: (vertex group, k-step of 4 features, lane)
+                V = int(v_shaped.shape[0])
+                lane = torch.arange(64, device=dev)
+                vert = (16 * torch.arange((V + 15) // 16, device=dev)[:, None, None] + lane % 16).clamp(max=V - 1)
+                feat = (4 * torch.arange(34, device=dev)[None, :, None] + lane // 16).clamp(max=134)
+                posedirs_lanes = self.posedirs.reshape(135, V, 3)[feat, vert].contiguous()
+                keep = dict(v_shaped=v_shaped.contiguous(), joints=joints.contiguous(), posedirs_lanes=posedirs_lanes,
                             posedirs=self.posedirs.contiguous(), weights=self.lbs_weights.contiguous(),
                             comps=comps.contiguous().float(), pose_mean=self.pose_mean.contiguous(),
                             parents=self.parents.to(torch.int32).contiguous(),
@@ -190,7 +196,8 @@ class MANO(nn.Module):
                               keep['joints'].data_ptr(), keep['posedirs'].data_ptr(), keep['weights'].data_ptr(),
                               keep['comps'].data_ptr(), keep['pose_mean'].data_ptr(), keep['parents'].data_ptr(),
                               keep['skin_joints'].data_ptr() if has_table else None,
-                              keep['skin_weights'].data_ptr() if has_table else None, width)
+                              keep['skin_weights'].data_ptr() if has_table else None, width,
+                              keep['posedirs_lanes'].data_ptr() if has_table else None)
             self._consts = (c, keep)
             self._consts_key = key
         return self._consts[0]

@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 111   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 112   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);
@@ -190,6 +190,10 @@ typedef struct {
     const unsigned char* skin_joints;
     const float* skin_weights;
     int skin_width;           /* 8 (vertices with more non-zero weights: leave the table NULL) */
+    /* optional copy of posedirs in the order the forward kernel's lanes read it, [ceil(V/16), 34, 64, 3]: entry
+     * (g, s, lane) holds the three coordinates of vertex min(16g + lane%16, V-1) for pose feature min(4s + lane/16, 134),
+     * so that one wave load is 768 contiguous bytes.  Used with the skinning table; NULL: the kernel reads posedirs. */
+    const float* posedirs_lanes;
 } DvqManoConsts;
 
 int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float* transl, int B,

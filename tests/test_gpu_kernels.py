@@ -60,6 +60,13 @@ def test_mano_skinning_table_equals_dense_weights():
     a = ops.mano_lbs(go, hp, tr, c, 778, want_v_posed=True)
     b = ops.mano_lbs(go, hp, tr, dense, 778, want_v_posed=True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    # the lane-ordered copy of posedirs holds the same numbers: with it absent the kernel reads posedirs itself
+    assert c.posedirs_lanes is not None
+    plain = DvqManoConsts()
+    ctypes.memmove(ctypes.byref(plain), ctypes.byref(c), ctypes.sizeof(c))
+    plain.posedirs_lanes = None
+    d = ops.mano_lbs(go, hp, tr, plain, 778, want_v_posed=True)
+    assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1]) and torch.equal(a[3], d[3])
 
 
 @pytest.mark.parametrize("B", [1, 3, 8, 9, 67])
