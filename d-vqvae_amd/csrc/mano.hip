@@ -26,6 +26,7 @@ constexpr int kMH = 16;       // hands per workgroup
 constexpr int kJ = 16;        // joints
 constexpr int kPF = 135;      // pose-feature length = 15 joints * 9
 constexpr int kKS = 34;       // MFMA k-steps of 4 over the pose features (135 + one zero)
+constexpr int kKSP = 36;      // k-steps of the lane-ordered copy of posedirs (the last two are zeros): three turns of a ring of 12
 constexpr int kManoThreads = 256;    // dense form: phase A uses all of them (hand x joint), phase B the first 48, phase C four waves
 constexpr int kSkinW = 8;     // slots per vertex in the skinning table
 
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     __shared__ __attribute__((aligned(16))) float sAp[kMH][kJ * 12 + 4];
     auto sA = [&](int hh, int jj) -> float* { return &sAp[hh][jj * 12]; };
     __shared__ float sT[kMH][kJ][12];    // world transforms, upper 3x4
-    __shared__ float sPF[kMH][kKS * 4];  // pose feature (R[1:] - I), zero-padded
+    __shared__ float sPF[kMH][kKSP * 4]; // pose feature (R[1:] - I), zero-padded
     __shared__ float sTr[kMH][4];        // translation (0 when absent)
     __shared__ float sHP[kMH][48];       // PCA coefficients of the block's hands
     __shared__ float sComps[45 * 45];    // PCA basis
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     // ---- A: full pose and Rodrigues, one thread per (hand, joint)   (lbs.py:167-198)
     if (tid < kMH * kJ) {
         const int hnd = tid / kJ, j = tid % kJ;
-        if (j == 0) sPF[hnd][kPF] = 0.f;
+        if (j < kKSP * 4 - kPF) sPF[hnd][kPF + j] = 0.f;
         if (hnd < nh) {
             const int b = b0 + hnd;
             float rv[3];
@@ -199,13 +200,13 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     auto load_chunk = [&](int g, int ci, f32x3* dst) {
         int vr = 16 * g + h;
         if (vr >= V) vr = V - 1;
-        const float* pd = LANES ? pd_lanes + ((int64_t)g * kKS * 64 + lane) * 3 : posedirs + 3 * (int64_t)vr;
+        const float* pd = posedirs + 3 * (int64_t)vr;
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             const int ks = ci * CH + s;
             if (ks < kKS) {
                 const int k = (4 * ks + q) < kPF ? (4 * ks + q) : kPF - 1;
-                dst[s] = *reinterpret_cast<const f32x3*>(LANES ? pd + ks * 192 : pd + k * prow);
+                dst[s] = *reinterpret_cast<const f32x3*>(pd + k * prow);
             }
         }
     };
@@ -226,9 +227,23 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
             vs[i] = *reinterpret_cast<const f32x3*>(v_shaped + (int64_t)v * 3);
         }
     };
+    // Lane-ordered posedirs: a ring of 12 k-steps in registers, refilled one k-step at a time right behind the products that
+    // free a slot, so that 11 loads (8.4 KB per wave) are in flight all the time -- during the skinning too.
+    constexpr bool RINGED = CHUNKED && LANES;
+    constexpr int RING = 12;
+    static_assert(kKSP % RING == 0, "a k-step keeps its ring slot from group to group");
+    f32x3 ring[RINGED ? RING : 1];
+    const float* pdl = LANES ? pd_lanes + lane * 3 : nullptr;
+    auto ring_load = [&](int g, int ks) { return *reinterpret_cast<const f32x3*>(pdl + ((int64_t)g * kKSP + ks) * 192); };
     if (wave < n_groups) {
-        if (CHUNKED) load_chunk(wave, 0, abuf[0]);
-        else load_group(wave);
+        if constexpr (RINGED) {
+#pragma unroll
+            for (int s = 0; s < RING - 1; ++s) ring[s] = ring_load(wave, s);
+        } else if (CHUNKED) {
+            load_chunk(wave, 0, abuf[0]);
+        } else {
+            load_group(wave);
+        }
     }
     for (int g = wave; g < n_groups; g += WAVES) {
         const int v0 = 16 * g;
@@ -236,7 +251,25 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
         f32x4 acc[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (CHUNKED) {
+        if constexpr (RINGED) {
+            // (the next group's loads are unconditional -- the last group re-reads itself -- and a scheduling barrier after
+            // every step keeps each load where it is written: left to itself the compiler sinks the loads next to their use)
+            const int gn = g + WAVES < n_groups ? g + WAVES : g;
+            float bfr[3];
+            bfr[0] = sPF[h][q];
+            bfr[1] = sPF[h][4 + q];
+#pragma unroll
+            for (int ks = 0; ks < kKSP; ++ks) {
+                const int nk = ks + RING - 1;          // goes into the slot the previous step freed
+                ring[nk % RING] = nk < kKSP ? ring_load(g, nk) : ring_load(gn, nk - kKSP);
+                if (ks + 2 < kKSP) bfr[(ks + 2) % 3] = sPF[h][4 * (ks + 2) + q];
+                const float bf = bfr[ks % 3];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[ks % RING].x, bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[ks % RING].y, bf, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[ks % RING].z, bf, acc[2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (CHUNKED) {
 #pragma unroll
             for (int ci = 0; ci < NCH; ++ci) {
                 // the next chunk (or the next group's first) is requested into the other buffer before this one is used

@@ -184,8 +184,9 @@ class MANO(nn.Module):
                 V = int(v_shaped.shape[0])
                 lane = torch.arange(64, device=dev)
                 vert = (16 * torch.arange((V + 15) // 16, device=dev)[:, None, None] + lane % 16).clamp(max=V - 1)
-                feat = (4 * torch.arange(34, device=dev)[None, :, None] + lane // 16).clamp(max=134)
-                posedirs_lanes = self.posedirs.reshape(135, V, 3)[feat, vert].contiguous()
+                feat = 4 * torch.arange(36, device=dev)[None, :, None] + lane // 16        # features >= 135: zeros
+                padded = torch.cat([self.posedirs.reshape(135, V, 3), self.posedirs.new_zeros(9, V, 3)])
+                posedirs_lanes = padded[feat, vert].contiguous()
                 keep = dict(v_shaped=v_shaped.contiguous(), joints=joints.contiguous(), posedirs_lanes=posedirs_lanes,
                             posedirs=self.posedirs.contiguous(), weights=self.lbs_weights.contiguous(),
                             comps=comps.contiguous().float(), pose_mean=self.pose_mean.contiguous(),

@@ -190,9 +190,10 @@ typedef struct {
     const unsigned char* skin_joints;
     const float* skin_weights;
     int skin_width;           /* 8 (vertices with more non-zero weights: leave the table NULL) */
-    /* optional copy of posedirs in the order the forward kernel's lanes read it, [ceil(V/16), 34, 64, 3]: entry
-     * (g, s, lane) holds the three coordinates of vertex min(16g + lane%16, V-1) for pose feature min(4s + lane/16, 134),
-     * so that one wave load is 768 contiguous bytes.  Used with the skinning table; NULL: the kernel reads posedirs. */
+    /* optional copy of posedirs in the order the forward kernel's lanes read it, [ceil(V/16), 36, 64, 3]: entry
+     * (g, s, lane) holds the three coordinates of vertex min(16g + lane%16, V-1) for pose feature 4s + lane/16, zeros for
+     * features >= 135 (the last two steps s are all zero), so that one wave load is 768 contiguous bytes and a step keeps
+     * its place in a ring of 12.  Used with the skinning table; NULL: the kernel reads posedirs. */
     const float* posedirs_lanes;
 } DvqManoConsts;
 
