@@ -29,8 +29,10 @@ constexpr int kKS = 34;       // MFMA k-steps of 4 over the pose features (135 +
 constexpr int kKSP = 36;      // k-steps of the lane-ordered copy of posedirs (the last two are zeros): three turns of a ring of 12
 constexpr int kManoThreads = 256;    // dense form: phase A uses all of them (hand x joint), phase B the first 48, phase C four waves
 constexpr int kSkinW = 8;     // slots per vertex in the skinning table
+constexpr int kSlotGroups = 128;   // vertex groups whose slot count is kept in LDS (2048 vertices; later groups take all slots)
 
 struct f32x3 { float x, y, z; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x4 f32x4u __attribute__((aligned(4)));   // four floats at any 4-byte boundary (a hand's rows start at multiples of 8 bytes)
 
 // TABLE: skinning weights come as kSkinW (joint, weight) slots per vertex; otherwise as the dense [V,16] matrix.
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     __shared__ float sComps[45 * 45];    // PCA basis
     __shared__ float sJ[kJ * 3];         // rest joints
     __shared__ int sPar[kJ];
+    __shared__ int sSlots[kSlotGroups];  // table form: slots in use by any vertex of a group of 16
     // per wave: a group's 16 hands x 16 vertices x 3 results on their way out (row padded from 48 so that the hands'
     // rows start on different banks); [..][0] takes the vertices, [..][1] the pre-skinning vertices
     __shared__ __attribute__((aligned(16))) float sOut[WAVES][2][kMH][52];
@@ -73,7 +76,24 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     for (int i = tid; i < ncomp * 45; i += THREADS) sComps[i] = comps[i];
     if (tid < kJ * 3) sJ[tid] = joints[tid];
     if (tid < kJ) sPar[tid] = parents[tid];
+    if (TABLE && tid < kSlotGroups) sSlots[tid] = 0;
     __syncthreads();
+    if (TABLE) {   // (joined with the other phases' results by the barrier after the Rodrigues phase)
+        for (int v = tid; v < V && v < 16 * kSlotGroups; v += THREADS) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(skin_weights + (int64_t)v * kSkinW);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(skin_weights + (int64_t)v * kSkinW + 4);
+            int cnt = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (w0[e] != 0.f) cnt = e + 1;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (w1[e] != 0.f) cnt = e + 5;
+            }
+            atomicMax(&sSlots[v >> 4], cnt);
+        }
+    }
 
     // ---- A: full pose and Rodrigues, one thread per (hand, joint)   (lbs.py:167-198)
     if (tid < kMH * kJ) {
@@ -299,17 +319,8 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
         if (!TABLE) load_skin(g);
         // this lane: hand h, vertices v0 + 4q + i (register i of the three tiles)
         const int64_t hb = (int64_t)(b0 + (h < nh ? h : 0)) * V;
-        // Table slots are non-zero first: the number of slots any lane of the wave still needs bounds the loop.
-        int n_slots = NSLOT;
-        if (TABLE) {
-            n_slots = 0;
-#pragma unroll
-            for (int e = 0; e < kSkinW; ++e) {
-                const bool any = sw[0][e / 4][e % 4] != 0.f || sw[1][e / 4][e % 4] != 0.f || sw[2][e / 4][e % 4] != 0.f ||
-                                 sw[3][e / 4][e % 4] != 0.f;
-                if (__ballot(any) != 0) n_slots = e + 1;
-            }
-        }
+        // Table slots are non-zero first: the number of slots any vertex of the group needs bounds the loop.
+        const int n_slots = TABLE ? (g < kSlotGroups ? __builtin_amdgcn_readfirstlane(sSlots[g]) : kSkinW) : NSLOT;
         if (h >= nh) continue;
         const bool full = v0 + 16 <= V;
         // T_i = sum_j w_j A_j over the slots (joints ascending), VP of the lane's four vertices side by side: the LDS reads
@@ -317,11 +328,12 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
         constexpr int VP = TABLE ? 2 : 1;
 #pragma unroll
         for (int i0 = 0; i0 < 4; i0 += VP) {
-        float T[VP][12];
+        // (kept as pairs of neighbours within a row, the order the LDS reads deliver: one packed multiply-add per pair)
+        f32x2 T2[VP][6];
 #pragma unroll
         for (int u = 0; u < VP; ++u)
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[u][e] = 0.f;
+            for (int e = 0; e < 6; ++e) T2[u][e] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < NSLOT; ++e) {
             if (e >= n_slots) break;
@@ -337,14 +349,20 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
 #pragma unroll
             for (int u = 0; u < VP; ++u) {
                 const float w = sw[i0 + u][e / 4][e % 4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    T[u][c] = __builtin_fmaf(w, A0[u][c], T[u][c]);
-                    T[u][4 + c] = __builtin_fmaf(w, A1[u][c], T[u][4 + c]);
-                    T[u][8 + c] = __builtin_fmaf(w, A2[u][c], T[u][8 + c]);
-                }
+                const f32x2 ww = {w, w};
+                T2[u][0] = __builtin_elementwise_fma(ww, f32x2{A0[u][0], A0[u][1]}, T2[u][0]);
+                T2[u][1] = __builtin_elementwise_fma(ww, f32x2{A0[u][2], A0[u][3]}, T2[u][1]);
+                T2[u][2] = __builtin_elementwise_fma(ww, f32x2{A1[u][0], A1[u][1]}, T2[u][2]);
+                T2[u][3] = __builtin_elementwise_fma(ww, f32x2{A1[u][2], A1[u][3]}, T2[u][3]);
+                T2[u][4] = __builtin_elementwise_fma(ww, f32x2{A2[u][0], A2[u][1]}, T2[u][4]);
+                T2[u][5] = __builtin_elementwise_fma(ww, f32x2{A2[u][2], A2[u][3]}, T2[u][5]);
             }
         }
+        float T[VP][12];
+#pragma unroll
+        for (int u = 0; u < VP; ++u)
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[u][e] = T2[u][e / 2][e % 2];
 #pragma unroll
         for (int u = 0; u < VP; ++u) {
             const int i = i0 + u;
