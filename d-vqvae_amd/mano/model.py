@@ -65,6 +65,17 @@ class _LbsFunction(torch.autograd.Function):
         return g_go, g_hp, (g_tr if ctx.has_transl else None), None
 
 
+def lane_ordered_posedirs(posedirs, V):
+    """posedirs [135, V*3] in the order the forward kernel's lanes read it, [ceil(V/16), 36, 64, 3]: entry (g, s, lane)
+    holds vertex min(16g + lane%16, V-1), pose feature 4s + lane//16 (zeros for features >= 135)."""
+    dev = posedirs.device
+    lane = torch.arange(64, device=dev)
+    vert = (16 * torch.arange((V + 15) // 16, device=dev)[:, None, None] + lane % 16).clamp(max=V - 1)
+    feat = 4 * torch.arange(36, device=dev)[None, :, None] + lane // 16
+    padded = torch.cat([posedirs.reshape(135, V, 3), posedirs.new_zeros(9, V, 3)])
+    return padded[feat, vert].contiguous()
+
+
 class MANO(nn.Module):
     NUM_BODY_JOINTS = 1
     NUM_HAND_JOINTS = 15
@@ -180,13 +191,7 @@ class MANO(nn.Module):
                 width = 8                                 # slots of the kernel's table; denser models take the dense path
                 has_table = int(nz.sum(1).max()) <= width
                 order = torch.argsort((~nz).to(torch.int8), dim=1, stable=True)[:, :width]
-                # posedirs once more in the order the kernel's lanes read it: (vertex group, k-step of 4 features, lane)
-                V = int(v_shaped.shape[0])
-                lane = torch.arange(64, device=dev)
-                vert = (16 * torch.arange((V + 15) // 16, device=dev)[:, None, None] + lane % 16).clamp(max=V - 1)
-                feat = 4 * torch.arange(36, device=dev)[None, :, None] + lane // 16        # features >= 135: zeros
-                padded = torch.cat([self.posedirs.reshape(135, V, 3), self.posedirs.new_zeros(9, V, 3)])
-                posedirs_lanes = padded[feat, vert].contiguous()
+                posedirs_lanes = lane_ordered_posedirs(self.posedirs, int(v_shaped.shape[0]))
                 keep = dict(v_shaped=v_shaped.contiguous(), joints=joints.contiguous(), posedirs_lanes=posedirs_lanes,
                             posedirs=self.posedirs.contiguous(), weights=self.lbs_weights.contiguous(),
                             comps=comps.contiguous().float(), pose_mean=self.pose_mean.contiguous(),

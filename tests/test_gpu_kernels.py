@@ -69,6 +69,41 @@ def test_mano_skinning_table_equals_dense_weights():
     assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1]) and torch.equal(a[3], d[3])
 
 
+
+@pytest.mark.parametrize("V", [778, 37, 16, 5])
+def test_mano_fewer_vertices_equal_the_first_vertices_of_the_full_model(V):
+    """A vertex depends on its own row of every table only: with the tables cut to the first V vertices (groups of 16
+    that end ragged, one group, less than one) the kernel must return the full model's first V vertices, bit for bit,
+    in the table form with and without the lane-ordered posedirs and in the dense form."""
+    import ctypes
+    from dvq_hip._lib import DvqManoConsts
+    from mano.model import lane_ordered_posedirs
+    rh = make_mano(1)
+    go, hp, tr = (t.to(DEV) for t in synth.mano_inputs(21, seed=9))
+    c = rh._device_consts()
+    keep = rh._consts[1]
+    full = ops.mano_lbs(go, hp, tr, c, 778, want_v_posed=True)
+    pd = keep["posedirs"].reshape(135, 778, 3)[:, :V].reshape(135, V * 3).contiguous()
+    cut = dict(v_shaped=keep["v_shaped"][:V].contiguous(), posedirs=pd, weights=keep["weights"][:V].contiguous(),
+               skin_joints=keep["skin_joints"][:V].contiguous(), skin_weights=keep["skin_weights"][:V].contiguous(),
+               posedirs_lanes=lane_ordered_posedirs(pd, V))
+    small = DvqManoConsts()
+    ctypes.memmove(ctypes.byref(small), ctypes.byref(c), ctypes.sizeof(c))
+    small.n_verts = V
+    small.v_shaped, small.posedirs, small.lbs_weights = cut["v_shaped"].data_ptr(), pd.data_ptr(), cut["weights"].data_ptr()
+    small.skin_joints, small.skin_weights = cut["skin_joints"].data_ptr(), cut["skin_weights"].data_ptr()
+    small.posedirs_lanes = cut["posedirs_lanes"].data_ptr()
+    for form in ("lanes", "table", "dense"):
+        if form == "table":
+            small.posedirs_lanes = None
+        if form == "dense":
+            small.skin_joints, small.skin_weights = None, None
+        out = ops.mano_lbs(go, hp, tr, small, V, want_v_posed=True)
+        assert torch.equal(out[0], full[0][:, :V]), (V, form)
+        assert torch.equal(out[3], full[3][:, :V]), (V, form)
+        assert torch.equal(out[1], full[1]), (V, form)
+
+
 @pytest.mark.parametrize("B", [1, 3, 8, 9, 67])
 def test_mano_batches_vs_oracle(B):
     rh = make_mano(1)
