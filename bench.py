@@ -379,6 +379,21 @@ def main():
         el = timed_steps(lambda: step("sampled"), 2, 1, device, barrier)
         variants[f"{oname}_prior_sampled"] = round(B * 2 / el, 1)
         dvq_hip.set_compute_dtype(gen.model, tdtype)
+        # The random-init object codebook sends every synthetic cloud to ONE class, the best case for the prior's
+        # per-class table reads.  Trained-like case: the object codebook set to the features of 128 of the batch's own
+        # clouds, so that the batch spreads over (up to) 128 classes; restored afterwards.
+        if args.prior == "sampled":
+            E6 = gen.model.vqvae6.vector_quantization.embedding.weight
+            saved = E6.detach().clone()
+            with torch.no_grad():
+                feat = gen.model.obj_encoder_type(obj)[0]
+                pick = torch.randperm(B, device=device, generator=torch.Generator(device).manual_seed(7))[:E6.shape[0]]
+                E6.copy_(feat[pick].to(E6.dtype))
+            el = timed_steps(lambda: step("sampled"), args.steps, 2, device, barrier)
+            variants[f"{args.dtype}_prior_sampled_diverse_classes"] = round(B * args.steps / el, 1)
+            variants["diverse_classes_in_batch"] = int(gen.model.last_idx6.unique().numel())
+            with torch.no_grad():
+                E6.copy_(saved)
         result["variants_grasps_per_s"] = variants
         pr = prior_roofline(gen, B, device)
         if pr is not None:

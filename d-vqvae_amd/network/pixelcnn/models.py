@@ -127,6 +127,11 @@ class GatedPixelCNN(nn.Module):
         self.vrow_min_rows = 3072              # fused vertical-row kernel (bf16) from this many rows per (sub-)batch
         self.class_rows = True                 # grid row 0's vertical stack and cell (0,0) once per class, not per row
         self.class_rows_min_rows = 1           # ... for batches of at least this many rows
+        # Rows of a batch evaluated in class order: a tile's epilogue then reads few rows of the per-class tables instead
+        # of one per sample (4096 grids of 128 classes drawn at random: 5.72 -> 5.50 ms; of one class: 5.27 -> 5.32 ms,
+        # the price of the sort and the two permutations).  Same grids row for row.
+        self.sort_by_class = True
+        self.sort_min_rows = 2048              # ... for batches of at least this many rows
 
     def forward(self, x, label):
         shp = x.size() + (-1,)
@@ -197,7 +202,7 @@ class GatedPixelCNN(nn.Module):
 
     @torch.no_grad()
     def generate(self, x_start, label, shape=(3, 3), batch_size=64, generator=None, return_probs=False,
-                 uniforms=None):
+                 uniforms=None, _sorted=False):
         """Sample a grid of indices, cell by cell in raster order (models.py:176-198).
         `x_start` is accepted and ignored, as in the reference.  Cell (i,j) is drawn from
         softmax(logits[:, :, i, j]) with torch.multinomial (optionally `generator`) or, when
@@ -213,6 +218,13 @@ class GatedPixelCNN(nn.Module):
         dev = self.embedding.weight.device
         if not self.embedding.weight.is_cuda:
             raise RuntimeError("GatedPixelCNN.generate needs the module on a HIP device (there is no CPU path)")
+        if self.sort_by_class and B >= self.sort_min_rows and uniforms is not None and not return_probs and not _sorted:
+            # rows are independent and a row's arithmetic does not depend on its position: same grids, row for row
+            lab, perm = torch.sort(label.reshape(-1).to(torch.int64))
+            xs = self.generate(x_start, lab, shape, B, generator, False, uniforms[perm], _sorted=True)
+            x = torch.empty_like(xs)
+            x[perm] = xs
+            return x
         self._prepared_hip()
         bufs = self._act_buffers(B, H, W, dev)
         bufs["label"].copy_(label.reshape(-1).to(torch.int64))

@@ -174,6 +174,29 @@ def test_prior_rows_by_class_equal_rows_evaluated_one_by_one(dtype):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prior_class_ordered_evaluation_gives_the_same_grids(dtype):
+    """From sort_min_rows rows on generate() evaluates the rows of a batch in class order and hands the grids back in
+    arrival order.  Rows are independent and a row's arithmetic does not depend on its position in the batch: the grids
+    are equal row for row -- with many classes, with one, and at a batch that is not a multiple of the tile height."""
+    from dvq_hip import rng
+    model, _ = build()
+    prior = model.GatedPixelCNN
+    prior.compute_dtype = dtype
+    assert prior.sort_by_class
+    prior.sort_min_rows = 256
+    for B, n_cls in ((1100, 128), (1100, 1), (512, 5)):
+        lab = torch.randint(0, n_cls, (B,), device=DEV, generator=torch.Generator(DEV).manual_seed(6)) + (128 - n_cls)
+        u = rng.uniforms(torch.arange(B, device=DEV) + 17, 9, seed=3)
+        grids = {}
+        for on in (True, False):
+            prior.sort_by_class = on
+            for _ in range(2):                      # the second call replays the recorded graph
+                grids[on] = prior.generate(None, lab, shape=(3, 3), batch_size=B, uniforms=u)
+        prior.sort_by_class = True
+        assert torch.equal(grids[True], grids[False]), (B, n_cls)
+
+
 def test_uniforms_kernel_equals_the_tensor_formulation():
     """dvq_prior_uniforms against dvq_hip.rng.uniforms (splitmix64 in wrapping int64 tensor arithmetic, also the CPU
     path): bit-equal for ids beyond 2^32, a negative-wrapping seed offset and a ragged count."""
