@@ -323,6 +323,20 @@ def main():
     ks = kernel_stats(f"pointnet_mlp_max[C=4,N={N}]")
     ops.enable_timers(False)
 
+    # The collective by itself: the same all-gather of one step's vertices with nothing beside it (in the timed
+    # steps it runs beside the next step's kernels), max over ranks.
+    gather_alone = None
+    if world > 1:
+        v = torch.randn((B, 778, 3), dtype=torch.float32, device=device)
+        el = timed_steps(lambda: parallel.gather_rows(v, world * B), args.steps, 2, device, barrier)
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item()) / args.steps * 1e3
+        recv = (world - 1) * B * 778 * 3 * 4
+        gather_alone = {"ms": round(ms, 4), "bytes_received_per_rank": recv, "GBs_received_per_rank": round(recv / ms / 1e6, 1),
+                        "note": "all-gather of one step's vertices alone, synchronous, nothing else on the device"}
+        del v
+
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -344,6 +358,8 @@ def main():
                        "tta_iterations": args.tta_iters, "weights": "random-init (seed 0), MANO-shaped synthetic hand model",
                        "parallelism": f"dp{world}"},
         }
+        if gather_alone is not None:
+            result["all_gather"] = gather_alone
         if ks is not None:
             avg_ms, launches, (kb, kc, kn), name, alone_ms = ks
             flops = float(kb) * kn * FLOP_PER_POINT[kc]
