@@ -988,6 +988,9 @@ static int launch_reg(const VqBatch& vb, int nb, const VqPlan& p, int64_t n, hip
     int TS = 65536 / TILE_BYTES;  // 64 KiB of codebook per stage
     if (TS < 1) TS = 1;
     if (TS > p.n_tiles) TS = p.n_tiles;
+    // a codebook of up to 144 KiB (fp32: the reference's 128 x 256) stays in LDS for the whole launch instead of being
+    // re-staged in two halves, with two barriers, for every 256 latents
+    if ((size_t)p.n_tiles * TILE_BYTES <= 144 * 1024) TS = p.n_tiles;
     const int n_stages = (p.n_tiles + TS - 1) / TS;
     const int n_buf = n_stages > 1 ? 2 : 1;
     const size_t lds = (size_t)n_buf * TS * TILE_BYTES + (size_t)n_buf * TS * 32 * 4;
