@@ -58,7 +58,7 @@ struct VqBatch {
     int64_t* idx[kVqMaxBatch];
 };
 
-constexpr int kVqRotMinTiles = 8;          // 256 codes: four stages of two tiles
+constexpr int kVqRotMinTiles = 9;          // (256 codes stay in LDS: one-sweep kernel)
 constexpr int kVqRotMaxTiles = 64;
 constexpr int64_t kVqRotMinRows = 65536;   // below this the one-sweep kernel has the lower fixed cost
 constexpr int64_t kVqTwoTileMaxRows = (int64_t)3 << 20;
@@ -1010,6 +1010,7 @@ static int launch_bf16x(const VqBatch& vb, int nb, const VqPlan& p, int64_t n, h
     int TS = (68 * 1024) / TILE_BYTES;   // 68-KiB stages: 4 groups of 32 codes at D=256
     if (TS < 1) TS = 1;
     if (TS > p.n_tiles) TS = p.n_tiles;
+    if ((size_t)p.n_tiles * TILE_BYTES <= 144 * 1024) TS = p.n_tiles;   // up to 256 codes of 256 dims stay in LDS
     const int n_stages = (p.n_tiles + TS - 1) / TS;
     const size_t lds = (size_t)(n_stages > 1 ? 2 : 1) * TS * TILE_BYTES;
     auto kern = vq_argmax_bf16_kernel<D, NB, WAVES>;
@@ -1046,6 +1047,10 @@ static int launch_fast(const VqBatch& vb, int nb, const VqPlan& p, int64_t n, in
         // of four, so two workgroups (16 waves) share a CU and one loads while the other computes -- 4.7 -> 5.0 TB/s
         // at 1 Mi latents, 3.4 -> 4.5 at 256 Ki; beyond a few Mi rows four tiles per wave are ahead again (5.2 vs 5.4).
         if (D == 256 && p.n_tiles <= 4 && n <= kVqTwoTileMaxRows) return launch_bf16x<256, 2, 8>(vb, nb, p, n, st);
+        // up to 256 codes stay in LDS too (136 KiB: one workgroup per CU): sixteen waves of two tiles, so that some waves
+        // load while others compute -- 1 Mi latents 0.148-0.184 ms with eight waves of four tiles, 0.132-0.156 ms with
+        // sixteen of two, alternating in one process; the rotating sweep used before: 0.16-0.18 ms
+        if (D == 256 && p.n_tiles <= 8) return launch_bf16x<256, 2, 16>(vb, nb, p, n, st);
         if (D == 256) return launch_bf16x<256, 4, 8>(vb, nb, p, n, st);
         if (D == 128) return launch_bf16x<128, 4, 8>(vb, nb, p, n, st);
         return launch_bf16x<64, 4, 8>(vb, nb, p, n, st);
