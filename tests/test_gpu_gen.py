@@ -289,6 +289,33 @@ def test_prior_products_tiled_and_k_split_kernels_agree(dtype):
         assert (small - big[sel]).abs().max().item() <= tol
 
 
+def test_prior_products_wide_layer_on_paired_128_feature_tiles():
+    """A 2048-feature product over 4096 rows (the head's hidden layer at the timed batch size) runs on eight-wave
+    workgroups of 256 features; the same rows in a 2048-row batch take 64-feature tiles in pairs.  Every output is the
+    same chain of fp32 sums in both: bit-equal, and equal to an fp64 product of the bf16-rounded operands."""
+    from dvq_hip import ops
+    code = ops.DVQ_BF16
+    g = torch.Generator(DEV).manual_seed(13)
+    V, d, N, M = 90, 128, 2048, 4096
+    table = torch.randn(V, d, device=DEV, generator=g)
+    idx = torch.randint(0, V, (M,), device=DEV, generator=g)
+    W = torch.randn(N, d, device=DEV, generator=g) * 0.1
+    bias = torch.randn(N, device=DEV, generator=g)
+    Wp = ops.prior_pack_weight(W, code)
+
+    def rows(m):
+        x = ops.prior_embed(idx[:m].contiguous(), table, ops.prior_packed_empty(m, d, DEV, True, code), code)
+        out = torch.empty(m, N, dtype=torch.float32, device=DEV)
+        ops.prior_gemm([ops.prior_job([(x, Wp, d // 32)], bias, out_rows=out)], m, N, ops.PRIOR_ROWS, True, table, code)
+        return out
+
+    big, half = rows(M), rows(M // 2)
+    assert torch.equal(big[:M // 2], half)
+    rnd = lambda t: t.to(torch.bfloat16).double()
+    want = (rnd(table)[idx] @ rnd(W).T + bias.double()).clamp_min(0)
+    assert (big.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
 def test_prior_sample_kernel_equals_softmax_cumsum_searchsorted():
     """The fused cell sampler against the torch formulation it replaces (softmax, renormalise, fp64 cumulative
     sum, searchsorted) and against prior_embed for the packed embedding rows."""
