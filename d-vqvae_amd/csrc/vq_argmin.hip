@@ -139,6 +139,13 @@ __device__ __forceinline__ void stage_copy(const char* __restrict__ src, char* d
     }
 }
 
+__device__ __forceinline__ void vq_glds16(const void* gsrc_lane, void* lds_wave_base);
+// one dword per lane straight into LDS (64 consecutive floats per wave-instruction)
+__device__ __forceinline__ void vq_glds4(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
 // ------------------------------------------------- fast path: z rows in registers
 // One wave owns NB*32 latents; their rows stay in registers for the whole sweep over
 // the codebook.  The codebook streams through LDS in stages of TS tiles (double
@@ -167,7 +174,20 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_reg_kernel(VqBatch vb, i
     constexpr int LAT_PER_BLOCK = WAVES * NB * 32;
     const int64_t n_groups = (n + LAT_PER_BLOCK - 1) / LAT_PER_BLOCK;
 
-    bool resident = false;  // single-stage codebooks are staged once per block
+    // A stage goes global -> LDS by direct copies (1-KiB units of codes dealt to the waves, then the stage's |E|^2, 64
+    // floats per wave-instruction): no registers and no wait between the request and the products of the current stage.
+    auto stage_dma = [&](int t_first, int t_count, int bufi) {
+        const char* src = packed + (int64_t)t_first * TILE_BYTES;
+        char* dst = e_lds + bufi * stage_bytes;
+        const int units = t_count * U;
+        for (int u = wave; u < units; u += WAVES) vq_glds16(src + (int64_t)u * 1024 + lane * 16, dst + u * 1024);
+        const int ne = t_count * 32;
+        for (int e0 = wave * 64; e0 < ne; e0 += WAVES * 64)
+            if (e0 + lane < ne) vq_glds4(e2 + t_first * 32 + e0 + lane, e2_lds + bufi * TS * 32 + e0);
+    };
+    bool staged = false;  // the first stage of the coming sweep is in LDS (or on its way): single-stage codebooks are staged
+                          // once per block, longer ones cycle -- the last stage of a sweep requests the first of the next
+    int g = 0;            // stages consumed so far by a multi-stage block: stage g sits in buffer g & 1
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t lat0 = grp * LAT_PER_BLOCK + (int64_t)wave * NB * 32;
         // ---- load this wave's latent rows into B-fragment registers, and |z|^2
@@ -208,23 +228,20 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_reg_kernel(VqBatch vb, i
         for (int nb = 0; nb < NB; ++nb) { best[nb].d = __builtin_inff(); best[nb].k = 0; }
 
         // ---- sweep the codebook
-        if (!resident) {
-            const int tiles0 = n_tiles < TS ? n_tiles : TS;
-            stage_copy(packed, e_lds, tiles0 * TILE_BYTES, tid, WAVES * 64);
-            stage_copy(reinterpret_cast<const char*>(e2), reinterpret_cast<char*>(e2_lds), tiles0 * 32 * 4, tid, WAVES * 64);
+        if (!staged) {
+            stage_dma(0, n_tiles < TS ? n_tiles : TS, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own copies landed before they are published
             __syncthreads();
-            resident = (n_stages == 1);
+            staged = true;
         }
         for (int st = 0; st < n_stages; ++st) {
-            const int buf = st & (n_buf - 1);
+            const int buf = g & (n_buf - 1);
             const int t_first = st * TS;
             const int t_count = (n_tiles - t_first) < TS ? (n_tiles - t_first) : TS;
-            if (st + 1 < n_stages) {  // prefetch the next stage into the other buffer
-                const int nf = (st + 1) * TS;
-                const int nc = (n_tiles - nf) < TS ? (n_tiles - nf) : TS;
-                stage_copy(packed + (int64_t)nf * TILE_BYTES, e_lds + (buf ^ 1) * stage_bytes, nc * TILE_BYTES, tid, WAVES * 64);
-                stage_copy(reinterpret_cast<const char*>(e2 + nf * 32), reinterpret_cast<char*>(e2_lds + (buf ^ 1) * TS * 32),
-                           nc * 32 * 4, tid, WAVES * 64);
+            if (n_stages > 1 && (st + 1 < n_stages || grp + gridDim.x < n_groups)) {
+                // the next stage into the other buffer; behind the last one, the first stage of the next sweep
+                const int nf = (st + 1 < n_stages ? st + 1 : 0) * TS;
+                stage_dma(nf, (n_tiles - nf) < TS ? (n_tiles - nf) : TS, buf ^ 1);
             }
             const char* eb = e_lds + buf * stage_bytes;
             const float* e2b = e2_lds + buf * TS * 32;
@@ -255,9 +272,12 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmin_reg_kernel(VqBatch vb, i
                 for (int nb = 0; nb < NB; ++nb)
                     scan_tile(acc[nb], e2b + t * 32, h, (t_first + t) * 32, z2[nb], best[nb]);
             }
-            if (n_stages > 1) __syncthreads();  // next buffer landed; this one may be overwritten
+            if (n_stages > 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own copies landed before they are published
+                __syncthreads();  // next buffer landed; this one may be overwritten
+                ++g;
+            }
         }
-        // a multi-stage sweep leaves the LAST stage in a buffer; the next group restages from 0
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             merge_halves(best[nb]);
