@@ -49,13 +49,19 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
     const int* __restrict__ order, float thresh, float penetr_scale, float contact_scale, float w_penetr,
     float w_contact, float* __restrict__ grad_verts, float* __restrict__ losses, int* __restrict__ nn_idx) {
     extern __shared__ __attribute__((aligned(16))) char tta_smem[];
-    f32x4* hv = reinterpret_cast<f32x4*>(tta_smem);                       // [k] x, y, z of vertex order[k]; w = order[k] as bits
-    f32x4* hn = hv + V;                                                  // [k] vertex normal (unnormalised)
-    long long* sumP = reinterpret_cast<long long*>(hn + V);              // [k][3] fixed-point sum of o_i, penetrating points
-    long long* sumC = sumP + 3 * V;                                      // [k][3] same, contact points
-    int* cntP = reinterpret_cast<int*>(sumC + 3 * V);
-    int* cntC = cntP + V;
-    int* rank = cntC + V;                                                // vertex id -> k
+    // Slots: the contact set in slots [0, nC), the other vertices from V1 = nC rounded up to a multiple of four, the whole
+    // rounded up again to Vp; the spare slots hold a point at infinity, so the scan reads four slots at a time from one
+    // address without clamping and a spare slot never wins.
+    const int V1 = (nC + 3) & ~3, Vp = V1 + ((V - nC + 3) & ~3);
+    f32x4* hv = reinterpret_cast<f32x4*>(tta_smem);                       // [slot] x, y, z of its vertex; w = vertex id as bits
+    f32x4* hn = hv + Vp;                                                 // [slot] vertex normal (unnormalised)
+    long long* sumP = reinterpret_cast<long long*>(hn + Vp);             // [slot][3] fixed-point sum of o_i, penetrating points
+    long long* sumC = sumP + 3 * Vp;                                     // [slot][3] same, contact points
+    int* cntP = reinterpret_cast<int*>(sumC + 3 * Vp);
+    int* cntC = cntP + Vp;
+    int* rank = cntC + Vp;                                               // vertex id -> slot
+    // slot -> position in `order`, or -1 for a spare slot
+    auto order_pos = [&](int slot) { return slot < nC ? slot : (slot >= V1 && slot - V1 < V - nC) ? nC + slot - V1 : -1; };
     __shared__ float sPen[kCgWaves], sCon[kCgWaves];
     __shared__ int sN[kCgWaves];
 
@@ -64,21 +70,29 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
     const float* vb = verts + (int64_t)b * V * 3;
     const float inf = __builtin_inff();
 
-    for (int k = tid; k < V; k += kCgThreads) {
-        const int v = order[k];
+    for (int k = tid; k < Vp; k += kCgThreads) {
+        const int op = order_pos(k);
         f32x4 h;
-        h[0] = vb[3 * v]; h[1] = vb[3 * v + 1]; h[2] = vb[3 * v + 2];
-        h[3] = __int_as_float(v);
+        if (op >= 0) {
+            const int v = order[op];
+            h[0] = vb[3 * v]; h[1] = vb[3 * v + 1]; h[2] = vb[3 * v + 2];
+            h[3] = __int_as_float(v);
+            rank[v] = k;
+        } else {
+            h[0] = h[1] = h[2] = inf;
+            h[3] = __int_as_float(0x7fffffff);
+        }
         hv[k] = h;
-        rank[v] = k;
         cntP[k] = 0; cntC[k] = 0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { sumP[3 * k + c] = 0; sumC[3 * k + c] = 0; }
     }
     __syncthreads();
     // vertex normals: sum of (p1 - p0) x (p2 - p0) over the incident faces
-    for (int k = tid; k < V; k += kCgThreads) {
-        const int v = order[k];
+    for (int k = tid; k < Vp; k += kCgThreads) {
+        const int op = order_pos(k);
+        if (op < 0) continue;
+        const int v = order[op];
         float nx = 0.f, ny = 0.f, nz = 0.f;
         for (int q = vf_ptr[v]; q < vf_ptr[v + 1]; ++q) {
             const int f = vf[q];
@@ -115,8 +129,7 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
                 f32x2 d[4][2];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int k = kg + u < k1 ? kg + u : k1 - 1;
-                    const f32x4 h = hv[k];
+                    const f32x4 h = hv[kg + u];
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         const f32x2 dx = px[g] - h[0], dy = py[g] - h[1], dz = pz[g] - h[2];
@@ -145,24 +158,24 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
             }
             return bk;
         };
-        scan(0, nC);
+        scan(0, V1);
         float cbest[kTtaPts];
         int ci[kTtaPts];
 #pragma unroll
-        for (int q = 0; q < kTtaPts; ++q) { cbest[q] = best[q >> 1][q & 1]; ci[q] = resolve(q, bi[q], nC); bi[q] = ci[q]; }
+        for (int q = 0; q < kTtaPts; ++q) { cbest[q] = best[q >> 1][q & 1]; ci[q] = resolve(q, bi[q], V1); bi[q] = ci[q]; }
         // the other vertices are scanned from scratch; the nearer of the two winners is the nearest vertex, and at
         // exactly equal distances the one with the lower vertex id (inside either part the order is ascending, so
         // the first met is the lowest): ties go to the lowest index, as a plain scan over all vertices would give
 #pragma unroll
-        for (int q = 0; q < kTtaPts; ++q) { best[q >> 1][q & 1] = inf; bi[q] = nC; }
-        scan(nC, V);
+        for (int q = 0; q < kTtaPts; ++q) { best[q >> 1][q & 1] = inf; bi[q] = V1; }
+        scan(V1, Vp);
         float bdist[kTtaPts];
 #pragma unroll
         for (int q = 0; q < kTtaPts; ++q) {
             bdist[q] = cbest[q];
             int win = ci[q];
             if (V > nC) {
-                const int other = resolve(q, bi[q], V);
+                const int other = resolve(q, bi[q], Vp);
                 const float d2 = best[q >> 1][q & 1];
                 const bool lower = __float_as_int(hv[other][3]) < __float_as_int(hv[ci[q]][3]);
                 if (d2 < cbest[q] || (d2 == cbest[q] && lower)) { win = other; bdist[q] = d2; }
@@ -209,7 +222,8 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
         losses[2 * b + 1] = nT > 0 ? contact_scale * conT / (float)nT : 0.f;
     }
     float* gb = grad_verts + (int64_t)b * V * 3;
-    for (int k = tid; k < V; k += kCgThreads) {
+    for (int k = tid; k < Vp; k += kCgThreads) {
+        if (order_pos(k) < 0) continue;
         const f32x4 h = hv[k];
         const int v = __float_as_int(h[3]);
         const int nP = cntP[k], nC2 = cntC[k];
@@ -674,7 +688,9 @@ extern "C" int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, 
     if (mesh->n_faces < 0 || !mesh->faces || !mesh->vert_face_ptr || !mesh->vert_face || !mesh->search_order)
         return fail(DVQ_EINVAL, "tta_contact_grad: incomplete hand mesh");
     if (mesh->n_contact < 1 || mesh->n_contact > mesh->n_verts) return fail(DVQ_EINVAL, "tta_contact_grad: empty contact set");
-    const size_t lds = (size_t)mesh->n_verts * (16 + 16 + 24 + 24 + 4 + 4 + 4);
+    // slots: contact set and the other vertices, each rounded up to a multiple of four (see the kernel)
+    const int slots = ((mesh->n_contact + 3) & ~3) + ((mesh->n_verts - mesh->n_contact + 3) & ~3);
+    const size_t lds = (size_t)slots * (16 + 16 + 24 + 24 + 4 + 4) + (size_t)mesh->n_verts * 4;
     if (lds > 150 * 1024) return fail(DVQ_EINVAL, "tta_contact_grad: hand mesh too large for LDS");
     // the kernel also holds a few hundred bytes of static LDS, so ask for what is needed, not for the whole array
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(tta_contact_grad_kernel), lds, "tta_contact_grad")) return rc;
