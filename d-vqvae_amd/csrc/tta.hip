@@ -38,6 +38,7 @@ constexpr int kTtaPts = 4;   // object points per thread and pass (two packed-fp
 // per CU) give each SIMD six waves to hide the LDS latency of the vertex reads behind other waves' arithmetic.
 constexpr int kCgThreads = 768;
 constexpr int kCgWaves = kCgThreads / 64;
+constexpr int kCgGroup = 8;    // hand vertices per scan step (one compare-select of the running minimum per step and point)
 
 // Vertices are searched in `order`: the n_contact vertices of the contact set first, then the others.
 // The nearest contact-set vertex is then simply the running minimum at the end of the first group, and
@@ -49,10 +50,10 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
     const int* __restrict__ order, float thresh, float penetr_scale, float contact_scale, float w_penetr,
     float w_contact, float* __restrict__ grad_verts, float* __restrict__ losses, int* __restrict__ nn_idx) {
     extern __shared__ __attribute__((aligned(16))) char tta_smem[];
-    // Slots: the contact set in slots [0, nC), the other vertices from V1 = nC rounded up to a multiple of four, the whole
-    // rounded up again to Vp; the spare slots hold a point at infinity, so the scan reads four slots at a time from one
+    // Slots: the contact set in slots [0, nC), the other vertices from V1 = nC rounded up to a whole group of kCgGroup, the whole
+    // rounded up again to Vp; the spare slots hold a point at infinity, so the scan reads a group's slots from one
     // address without clamping and a spare slot never wins.
-    const int V1 = (nC + 3) & ~3, Vp = V1 + ((V - nC + 3) & ~3);
+    const int V1 = (nC + kCgGroup - 1) / kCgGroup * kCgGroup, Vp = V1 + (V - nC + kCgGroup - 1) / kCgGroup * kCgGroup;
     f32x4* hv = reinterpret_cast<f32x4*>(tta_smem);                       // [slot] x, y, z of its vertex; w = vertex id as bits
     f32x4* hn = hv + Vp;                                                 // [slot] vertex normal (unnormalised)
     long long* sumP = reinterpret_cast<long long*>(hn + Vp);             // [slot][3] fixed-point sum of o_i, penetrating points
@@ -122,35 +123,44 @@ __global__ __launch_bounds__(kCgThreads, 6) void tta_contact_grad_kernel(
             best[q >> 1][q & 1] = inf;
             bi[q] = 0;
         }
-        // Four vertices at a time: only the group's minimum is compared with the running best and only
-        // the group's first vertex is remembered; the winner inside the group is resolved after the scan.
+        // kCgGroup vertices at a time, four and four: only the group's minimum is compared with the running best and
+        // only the group's first slot is remembered; the winner inside the group is resolved after the scan.
         auto scan = [&](int k0, int k1) {
-            for (int kg = k0; kg < k1; kg += 4) {
-                f32x2 d[4][2];
+            for (int kg = k0; kg < k1; kg += kCgGroup) {
+                float m[kTtaPts];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f32x4 h = hv[kg + u];
+                for (int half = 0; half < kCgGroup / 4; ++half) {
+                    f32x2 d[4][2];
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const f32x2 dx = px[g] - h[0], dy = py[g] - h[1], dz = pz[g] - h[2];
-                        d[u][g] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    for (int u = 0; u < 4; ++u) {
+                        const f32x4 h = hv[kg + 4 * half + u];
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const f32x2 dx = px[g] - h[0], dy = py[g] - h[1], dz = pz[g] - h[2];
+                            d[u][g] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                        }
                     }
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float mh = fminf(fminf(d[0][g][e], d[1][g][e]), fminf(d[2][g][e], d[3][g][e]));
+                            m[2 * g + e] = half == 0 ? mh : fminf(m[2 * g + e], mh);
+                        }
                 }
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const float m = fminf(fminf(d[0][g][e], d[1][g][e]), fminf(d[2][g][e], d[3][g][e]));
-                        if (m < best[g][e]) { best[g][e] = m; bi[2 * g + e] = kg; }
-                    }
+                    for (int e = 0; e < 2; ++e)
+                        if (m[2 * g + e] < best[g][e]) { best[g][e] = m[2 * g + e]; bi[2 * g + e] = kg; }
             }
         };
-        // first vertex of the group [kg, min(kg+4, k1)) at the group's minimum distance
+        // first slot of the group [kg, kg + kCgGroup) at the group's minimum distance
         auto resolve = [&](int q, int kg, int k1) {
             const float ox = px[q >> 1][q & 1], oy = py[q >> 1][q & 1], oz = pz[q >> 1][q & 1];
             float bd = inf;
             int bk = kg;
-            for (int k = kg; k < kg + 4 && k < k1; ++k) {
+            for (int k = kg; k < kg + kCgGroup && k < k1; ++k) {
                 const f32x4 h = hv[k];
                 const float dx = ox - h[0], dy = oy - h[1], dz = oz - h[2];
                 const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -688,8 +698,8 @@ extern "C" int dvq_tta_contact_grad(const float* obj, int64_t obj_batch_stride, 
     if (mesh->n_faces < 0 || !mesh->faces || !mesh->vert_face_ptr || !mesh->vert_face || !mesh->search_order)
         return fail(DVQ_EINVAL, "tta_contact_grad: incomplete hand mesh");
     if (mesh->n_contact < 1 || mesh->n_contact > mesh->n_verts) return fail(DVQ_EINVAL, "tta_contact_grad: empty contact set");
-    // slots: contact set and the other vertices, each rounded up to a multiple of four (see the kernel)
-    const int slots = ((mesh->n_contact + 3) & ~3) + ((mesh->n_verts - mesh->n_contact + 3) & ~3);
+    // slots: contact set and the other vertices, each rounded up to whole scan groups (see the kernel)
+    const int slots = (mesh->n_contact + kCgGroup - 1) / kCgGroup * kCgGroup + (mesh->n_verts - mesh->n_contact + kCgGroup - 1) / kCgGroup * kCgGroup;
     const size_t lds = (size_t)slots * (16 + 16 + 24 + 24 + 4 + 4) + (size_t)mesh->n_verts * 4;
     if (lds > 150 * 1024) return fail(DVQ_EINVAL, "tta_contact_grad: hand mesh too large for LDS");
     // the kernel also holds a few hundred bytes of static LDS, so ask for what is needed, not for the whole array
