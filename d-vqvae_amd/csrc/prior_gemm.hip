@@ -1008,6 +1008,15 @@ extern "C" int dvq_prior_gemm(const DvqPriorJob* jobs, int n_jobs, int M, int N,
     // the residual 1x1 products are too small for two 64-wide workgroups per CU: 32-wide tiles (neutral at 4096 rows,
     // 5.46 -> 5.32 ms per 2048 grids)
     const bool one = !eight && no == 2 && dtype == DVQ_BF16 && epilogue == PG_PACK && (int64_t)(N / 64) * gy * n_jobs < want;
+    // ... unless 64-wide tiles on eight waves (two groups of 32 features sharing the activations, two waves per SIMD) still
+    // give every CU a workgroup: 40 % fewer operand bytes than the 32-wide tiles (5.33 -> 5.29 ms per 4096 grids)
+    if (one && (int64_t)(N / 64) * gy * n_jobs >= kNumCU) {
+        const dim3 grid2(N / 64, gy, n_jobs);
+        const size_t lds2 = (size_t)DVQ_PG_RING8 * (2 * 1 * ks * upb + 4 * ks * upb) * 1024;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prior_gemm_kernel<DVQ_BF16, PG_PACK, 1, 2, 2>), lds2, "prior_gemm")) return rc;
+        hipLaunchKernelGGL((prior_gemm_kernel<DVQ_BF16, PG_PACK, 1, 2, 2>), grid2, dim3(512), lds2, st, dev, M, N, relu);
+        return check_launch("prior_gemm");
+    }
     if (one) {
         const dim3 grid1(N / 32, gy, n_jobs);
         const size_t lds1 = (size_t)kPgRing * (1 * ks * upb + 4 * ks * upb) * 1024;
