@@ -15,13 +15,7 @@ from .mano_io import Struct
 
 def assemble_param(recon: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
     """[betas10 | global_orient3 | pose45 | transl3]  (gen_diverse_grasp_obman.py:243-247)"""
-    B = recon.shape[0]
-    p = torch.empty((B, 61), dtype=recon.dtype, device=recon.device)
-    p[:, 0:10] = recon[:, 0:10]
-    p[:, 10:13] = pos[:, 0:3]
-    p[:, 13:58] = recon[:, 10:55]
-    p[:, 58:61] = pos[:, 3:6]
-    return p
+    return torch.cat([recon[:, 0:10], pos[:, 0:3], recon[:, 10:55], pos[:, 3:6]], 1)     # one launch
 
 
 class GraspGenerator:
