@@ -205,17 +205,22 @@ def mano_model_data(seed: int = 0) -> Dict[str, np.ndarray]:
 
 
 def mano_state_dict(seed: int = 0, batch_size: int = 1, num_pca_comps: int = 45, flat_hand_mean: bool = True,
-                    prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
+                    prefix: str = "", data=None) -> "OrderedDict[str, torch.Tensor]":
     """The 14 tensors MANO(...) registers (mano/model.py:170-276), built from
-    mano_model_data(seed) exactly as the reference constructor derives them."""
-    d = mano_model_data(seed)
-    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    mano_model_data(seed) -- or from `data`, a dict of the same fields read from a model file --
+    exactly as the reference constructor derives them."""
+    d = mano_model_data(seed) if data is None else data
+
+    def f32(a):
+        if hasattr(a, "todense"):                  # the joint regressor of the official files is a sparse matrix
+            a = a.todense()
+        return torch.from_numpy(np.array(a, dtype=np.float32))
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     sd["betas"] = torch.zeros(batch_size, 10)
     sd["global_orient"] = torch.zeros(batch_size, 3)
     sd["transl"] = torch.zeros(batch_size, 3)
     sd["hand_pose"] = torch.zeros(batch_size, num_pca_comps)
-    sd["faces_tensor"] = torch.from_numpy(d["f"].astype(np.int64))
+    sd["faces_tensor"] = torch.from_numpy(np.asarray(d["f"]).astype(np.int64))
     sd["v_template"] = f32(d["v_template"])
     sd["shapedirs"] = f32(d["shapedirs"])
     sd["J_regressor"] = f32(d["J_regressor"])
@@ -223,7 +228,7 @@ def mano_state_dict(seed: int = 0, batch_size: int = 1, num_pca_comps: int = 45,
     par = torch.tensor(MANO_PARENTS, dtype=torch.int64)
     sd["parents"] = par
     sd["lbs_weights"] = f32(d["weights"])
-    sd["hand_components"] = f32(d["hands_components"][:num_pca_comps])
+    sd["hand_components"] = f32(np.asarray(d["hands_components"])[:num_pca_comps])
     hm = np.zeros_like(d["hands_mean"]) if flat_hand_mean else d["hands_mean"]
     sd["hand_mean"] = f32(hm)
     sd["pose_mean"] = torch.cat([torch.zeros(3), f32(hm)])
@@ -278,6 +283,28 @@ def vq_case(K: int, D: int, n: int, dist: str = "A", seed: int = 0):
         z = (E[j] + 0.3 * r.standard_normal(size=(n, D))).astype(np.float32)
     else:
         raise ValueError(dist)
+    return torch.from_numpy(z), torch.from_numpy(E)
+
+
+def vq_near_tie_case(K: int, D: int, n: int, kind: str, seed: int = 0):
+    """Latents built so that the two best codes are nearly equidistant, i.e. where the order in which the
+    reference rounds its distance (quantizer.py:46-48: fl(fl(|z|^2 + |E|^2) - 2 z.E)) decides the index.
+    kind 'mid'    : E ~ N(0,1); z = (E[a] + E[b]) / 2 + eps N(0,1), a != b.  The exact gap between codes a and b is
+                    2 eps n.(E[b] - E[a]); eps = 1e-5 puts it around the fp32 spacing of |z|^2 + |E|^2 (~3e-5 near 430).
+    kind 'bignorm': reference initialisation E ~ U(-1/K, 1/K) with |z|^2 ~ 4096 >> |E|^2 ~ D / (3 K^2): the code
+                    norms and most of the products vanish below the spacing of |z|^2 (4.9e-4)."""
+    r = _rng(seed, f"vqtie{K}x{D}{kind}")
+    if kind == "mid":
+        E = r.standard_normal(size=(K, D)).astype(np.float32)
+        a = r.integers(0, K, size=n)
+        b = (a + 1 + r.integers(0, K - 1, size=n)) % K
+        mid = 0.5 * (E[a].astype(np.float64) + E[b].astype(np.float64))
+        z = (mid + 1e-5 * r.standard_normal(size=(n, D))).astype(np.float32)
+    elif kind == "bignorm":
+        E = r.uniform(-1.0 / K, 1.0 / K, size=(K, D)).astype(np.float32)
+        z = (4.0 * r.standard_normal(size=(n, D))).astype(np.float32)
+    else:
+        raise ValueError(kind)
     return torch.from_numpy(z), torch.from_numpy(E)
 
 

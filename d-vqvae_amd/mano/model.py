@@ -14,7 +14,6 @@ change the mesh -- the reference hands lbs the module's own `betas` parameter
 (model.py:335), which every call site leaves at zero.  Unlike the reference, the call
 batch does not have to equal the constructor's batch_size.
 """
-import os
 import os.path as osp
 from collections import namedtuple
 
@@ -65,6 +64,26 @@ class _LbsFunction(torch.autograd.Function):
         return g_go, g_hp, (g_tr if ctx.has_transl else None), None
 
 
+def model_file_for(model_path, is_rhand, ext):
+    """(file to read, handedness): a directory stands for the MANO_RIGHT / MANO_LEFT file inside it; a file's own name
+    says which hand it is (mano/model.py:141-148)."""
+    if osp.isdir(model_path):
+        side = 'RIGHT' if is_rhand else 'LEFT'
+        return osp.join(model_path, f'MANO_{side}.{ext}'), is_rhand
+    return model_path, 'RIGHT' in osp.basename(model_path)
+
+
+def skinning_table(lbs_weights, width=8):
+    """Per vertex, the joints with a non-zero skinning weight in ascending order and their weights, zero-padded to
+    `width` slots: (fits, joints uint8 [V, width], weights [V, width]).  `fits` is False when some vertex has more
+    non-zero weights than slots (the kernel then takes the dense weight matrix).  The terms the table leaves out of the
+    dense sum over 16 joints are exact zeros, so both forms give the same bits."""
+    nz = lbs_weights != 0
+    fits = int(nz.sum(1).max()) <= width
+    order = torch.argsort((~nz).to(torch.int8), dim=1, stable=True)[:, :width]
+    return fits, order.to(torch.uint8).contiguous(), torch.gather(lbs_weights, 1, order).contiguous()
+
+
 def lane_ordered_posedirs(posedirs, V):
     """posedirs [135, V*3] in the order the forward kernel's lanes read it, [ceil(V/16), 36, 64, 3]: entry (g, s, lane)
     holds vertex min(16g + lane%16, V-1), pose feature 4s + lane//16 (zeros for features >= 135)."""
@@ -87,15 +106,15 @@ class MANO(nn.Module):
                  create_hand_pose=True, hand_pose=None, use_pca=True, num_pca_comps=6, flat_hand_mean=False,
                  batch_size=1, joint_mapper=None, v_template=None, dtype=torch.float32, vertex_ids=None,
                  use_compressed=True, ext='pkl', **kwargs):
+        side = None
         if data_struct is None:
-            if osp.isdir(model_path):
-                mano_path = os.path.join(model_path, 'MANO_{}.{}'.format('RIGHT' if is_rhand else 'LEFT', ext))
-            else:
-                mano_path = model_path
-                self.is_rhand = 'RIGHT' in os.path.basename(model_path)
-            assert osp.exists(mano_path), 'Path {} does not exist!'.format(mano_path)
+            mano_path, side = model_file_for(model_path, is_rhand, ext)
+            if not osp.exists(mano_path):
+                raise AssertionError(f'Path {mano_path} does not exist!')      # the reference asserts here
             data_struct = Struct(**read_model_file(mano_path))
         super().__init__()
+        if side is not None and not osp.isdir(model_path):
+            self.is_rhand = side
         if dtype != torch.float32:
             raise NotImplementedError("the HIP MANO kernel computes in float32")
         self.tip_ids = TIP_IDS['mano']
@@ -151,21 +170,23 @@ class MANO(nn.Module):
         self._consts = None
 
     def get_num_verts(self):
-        return self.v_template.shape[0]
+        return int(self.v_template.size(0))
 
     def get_num_faces(self):
-        return self.faces.shape[0]
+        return len(self.faces)
 
     def extra_repr(self):
-        msg = 'Number of betas: {}'.format(self.NUM_BETAS)
+        lines = [f'Number of betas: {self.NUM_BETAS}']
         if self.use_pca:
-            msg += '\nNumber of PCA components: {}'.format(self.num_pca_comps)
-        return msg + '\nFlat hand mean: {}'.format(self.flat_hand_mean)
+            lines.append(f'Number of PCA components: {self.num_pca_comps}')
+        lines.append(f'Flat hand mean: {self.flat_hand_mean}')
+        return '\n'.join(lines)
 
     def add_joints(self, vertices, joints, joint_ids=None):
-        if joint_ids is None:
-            joint_ids = torch.tensor(list(self.tip_ids.values()), dtype=torch.long, device=vertices.device)
-        return torch.cat([joints, torch.index_select(vertices, 1, joint_ids)], dim=1)
+        """joints followed by the vertices `joint_ids` (default: the five fingertips), [B, 16 + len(ids), 3]."""
+        ids = list(self.tip_ids.values()) if joint_ids is None else joint_ids
+        ids = torch.as_tensor(ids, dtype=torch.long, device=vertices.device)
+        return torch.cat((joints, vertices[:, ids]), dim=1)
 
     def _device_consts(self):
         """Constant tables for the kernel.  The shape term uses the module's own betas
@@ -186,18 +207,14 @@ class MANO(nn.Module):
                     v_shaped = self.v_template.clone()
                 joints = torch.einsum('ik,ji->jk', v_shaped, self.J_regressor)
                 comps = self.hand_components if self.use_pca else torch.eye(45, device=dev)
-                # the non-zero skinning weights of every vertex (1-6 of 16), joints ascending, zero-padded to one width
-                nz = self.lbs_weights != 0
                 width = 8                                 # slots of the kernel's table; denser models take the dense path
-                has_table = int(nz.sum(1).max()) <= width
-                order = torch.argsort((~nz).to(torch.int8), dim=1, stable=True)[:, :width]
+                has_table, skin_joints, skin_weights = skinning_table(self.lbs_weights, width)
                 posedirs_lanes = lane_ordered_posedirs(self.posedirs, int(v_shaped.shape[0]))
                 keep = dict(v_shaped=v_shaped.contiguous(), joints=joints.contiguous(), posedirs_lanes=posedirs_lanes,
                             posedirs=self.posedirs.contiguous(), weights=self.lbs_weights.contiguous(),
                             comps=comps.contiguous().float(), pose_mean=self.pose_mean.contiguous(),
                             parents=self.parents.to(torch.int32).contiguous(),
-                            skin_joints=order.to(torch.uint8).contiguous(),
-                            skin_weights=torch.gather(self.lbs_weights, 1, order).contiguous())
+                            skin_joints=skin_joints, skin_weights=skin_weights)
             c = DvqManoConsts(int(v_shaped.shape[0]), int(comps.shape[0]), keep['v_shaped'].data_ptr(),
                               keep['joints'].data_ptr(), keep['posedirs'].data_ptr(), keep['weights'].data_ptr(),
                               keep['comps'].data_ptr(), keep['pose_mean'].data_ptr(), keep['parents'].data_ptr(),

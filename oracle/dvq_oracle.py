@@ -99,11 +99,16 @@ def vq_dist_fp64_at(z: np.ndarray, E: np.ndarray, idx: np.ndarray) -> np.ndarray
     return ((z - e) ** 2).sum(1)
 
 
-def vq_tau(z: np.ndarray, E: np.ndarray, ulps: float = 4.0) -> np.ndarray:
-    """Near-tie threshold per row: `ulps` fp32 ulps of (|z|^2 + max|E|^2), the magnitude
-    at which the reference rounds its distances before the argmin."""
+def vq_tau(z: np.ndarray, E: np.ndarray, ulps: Optional[float] = None) -> np.ndarray:
+    """Near-tie threshold per row: `ulps` fp32 spacings of (|z|^2 + max|E|^2), the magnitude at which the reference
+    rounds its distances before the argmin (quantizer.py:46-48).  Default: max(4, sqrt(D)) spacings.  The reference's
+    own indices leave the exact minimum by up to 7.9 spacings at D = 256 on latents placed between two codes
+    (tests/golden/vq_near.npz): its fp32 matrix product carries the rounding of D accumulations, which grows like
+    sqrt(D), so a fixed threshold of a few spacings would reject the reference itself."""
     z = np.asarray(z, dtype=np.float64)
     E = np.asarray(E, dtype=np.float64)
+    if ulps is None:
+        ulps = max(4.0, float(np.sqrt(E.shape[1])))
     mag = (z * z).sum(1) + (E * E).sum(1).max()
     return ulps * np.spacing(mag.astype(np.float32)).astype(np.float64)
 

@@ -13,8 +13,9 @@ Shims applied to make the reference run on a CPU-only box (none edits a referenc
   * network.vqvae.quantizer.device (module global 'cuda', quantizer.py:7) -> cpu
   * Tensor.to('cuda') inside GenNet.gen (gen_net.py:79) is redirected to the cpu
   * `trimesh` (imported by mano/utils.py:23 for visualisation only) is stubbed
-  * MANO is constructed through its own `data_struct=` argument from a synthetic
-    MANO-shaped model: the licensed MANO_RIGHT.pkl is a pickle and is not loaded
+  * MANO is constructed through its own `data_struct=` argument: from a synthetic
+    MANO-shaped model for the committed fixtures; for the uncommitted `mano_real` step from
+    the arrays of the licensed MANO_RIGHT.pkl, read as data (never unpickled)
   * DVQVAE.forward reads an undefined global `f0hand` (DVQVAE.py:93); the complement of
     the five listed vertex sets in range(778) is injected (a documented reconstruction)
   * GenNet.gen only works at batch 1 (quantizer.py:70-74), so batches are B=1 loops
@@ -85,13 +86,16 @@ def ref_mano(ref, seed, batch_size):
                          batch_size=batch_size, flat_hand_mean=True)
 
 
+OUT_DIR = HERE
+
+
 def save(name, **arrays):
     out = {}
     for k, v in arrays.items():
         if torch.is_tensor(v):
             v = v.detach().cpu().numpy()
         out[k] = np.asarray(v)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
@@ -126,6 +130,37 @@ def golden_vq(ref):
         e = vq.get_emb(torch.tensor([9]), 256)
     out["get_emb_9"] = e.numpy()
     save("vq", **out)
+
+
+VQ_NEAR_CASES = [(128, 256), (512, 256)]
+
+
+def golden_vq_near_ties(ref):
+    """The reference quantizer on latents whose two best codes are nearly equidistant (synth.vq_near_tie_case):
+    rows whose exact gap is below a few fp32 spacings of |z|^2 + |E|^2 are the ones on which the evaluation order
+    of quantizer.py:46-48 decides.  Stored: the reference's indices; printed: how many rows are near-ties under the
+    rule of tests/parity.py and on how many the reference itself leaves the exact (fp64) minimum."""
+    sys.path.insert(0, ROOT)
+    from oracle import dvq_oracle as O
+    out = {}
+    for K, D in VQ_NEAR_CASES:
+        for kind in ("mid", "bignorm"):
+            z, E = synth.vq_near_tie_case(K, D, VQ_N, kind, seed=0)
+            vq = ref.quantizer.VectorQuantizer(K, D, 0.25, 1)
+            vq.embedding.weight.data.copy_(E)
+            with torch.no_grad():
+                idx, zq = vq(z, False)
+            assert torch.equal(zq, E[idx[:, 0]])
+            best, _, gap = O.vq_gap_fp64(z.numpy(), E.numpy())
+            tau = O.vq_tau(z.numpy(), E.numpy())
+            near = int((gap <= tau).sum())
+            off = int((idx[:, 0].numpy() != best).sum())
+            print(f"near-tie case K={K} D={D} {kind}: {near} of {VQ_N} rows within tau, reference != exact argmin on {off}")
+            assert near > 0
+            out[f"idx_{K}_{D}_{kind}"] = idx[:, 0].numpy().astype(np.int32)
+            out[f"near_{K}_{D}_{kind}"] = np.int32(near)
+            out[f"ref_off_exact_{K}_{D}_{kind}"] = np.int32(off)
+    save("vq_near", **out)
 
 
 def real_clouds():
@@ -252,6 +287,38 @@ def golden_mano_hmdo(ref):
                     os.path.join(HERE, "hmdo_obj_id_0.json"))
 
 
+MANO_DIR = os.path.join(REF, "DVQ-VAE", "models", "mano")
+
+
+def golden_mano_real(ref):
+    """The reference MANO class on the constants of the official right-hand model file that ships in the reference
+    tree, for the 123 rows of golden_mano_hmdo.  The file is under the MANO licence: nothing derived from it is
+    committed -- this step is run on demand by tests/test_real_mano_constants.py, which points OUT_DIR at a temporary
+    directory.  The file is a pickle; it is read as data by dvq_hip.mano_io (which neither imports nor calls anything
+    the file names) and handed to the reference class through its own `data_struct=` argument, the path
+    mano/model.py:140-158 takes after its pickle.load."""
+    from dvq_hip import mano_io
+    data = mano_io.read_model_file(os.path.join(MANO_DIR, "MANO_RIGHT.pkl"))
+    params, _, _, _ = hmdo_records()
+    p = torch.from_numpy(params.astype(np.float32))
+    extra = p[:3].clone()
+    extra[0, 10:] = 0
+    extra[1, 13:58] *= 3.0
+    extra[2, 10:13] = torch.tensor([3.1, -3.1, 3.1])
+    p = torch.cat([p, extra])
+    m = ref.mano.MANO(model_path="", data_struct=ref.mutils.Struct(**data), use_pca=True, num_pca_comps=45,
+                      batch_size=p.shape[0], flat_hand_mean=True).eval()
+    sd = m.state_dict()
+    mine = synth.mano_state_dict(batch_size=p.shape[0], data=data)
+    assert list(sd.keys()) == list(mine.keys())
+    for k in sd:
+        assert sd[k].dtype == mine[k].dtype and torch.equal(sd[k], mine[k]), k
+    with torch.no_grad():
+        o = m(betas=p[:, :10].clone(), global_orient=p[:, 10:13].clone(), hand_pose=p[:, 13:58].clone(),
+              transl=p[:, 58:].clone())
+    save("mano_real", recon_params=p, joints=o.joints, vertices=o.vertices)
+
+
 def golden_gen(ref, n_obj=16):
     sd = synth.gennet_state_dict(0, with_prior=True)
     model = ref.gn.GenNet()
@@ -323,15 +390,22 @@ def golden_dvqvae(ref):
     save("dvqvae", f0hand=np.array(f0, np.int32), hand_xyz=hand, emb_idx=emb_idx, obj_emb=obj_emb)
 
 
+STEPS = ("vq", "vq_near_ties", "pointnet", "mlp", "mano", "mano_hmdo", "dvqvae", "gen")
+
+
 def main():
+    """All committed fixtures, or only the named steps: `make_golden.py vq_near_ties mano`; `--out DIR` writes
+    somewhere else (used for `mano_real`, whose output is not committed)."""
+    global OUT_DIR
+    args = sys.argv[1:]
+    if "--out" in args:
+        i = args.index("--out")
+        OUT_DIR = args[i + 1]
+        del args[i:i + 2]
+    from dvq_hip import mano_io  # noqa: F401  (before the reference's packages take over the import path)
     ref = import_reference()
-    golden_vq(ref)
-    golden_pointnet(ref)
-    golden_mlp(ref)
-    golden_mano(ref)
-    golden_mano_hmdo(ref)
-    golden_dvqvae(ref)
-    golden_gen(ref)
+    for step in (args or STEPS):
+        globals()["golden_" + step](ref)
 
 
 if __name__ == "__main__":

@@ -5,10 +5,11 @@ import torch
 from oracle import dvq_oracle as O
 
 
-def check_vq_rows(z, E, idx, ref_idx, ulps=4.0):
+def check_vq_rows(z, E, idx, ref_idx, ulps=None):
     """Index parity rule: equal to the reference wherever the exact (fp64) best-vs-second
-    gap exceeds tau = `ulps` fp32 ulps of |z|^2+max|E|^2; on the remaining near-tie rows
-    the chosen code must itself be within tau of the exact minimum.
+    gap exceeds tau = `ulps` fp32 spacings of |z|^2+max|E|^2 (default max(4, sqrt(D)), see
+    oracle.dvq_oracle.vq_tau for why it grows with the row width); on the remaining near-tie
+    rows the chosen code must itself be within tau of the exact minimum.
     Returns the number of near-tie rows that differ."""
     z = z.numpy() if torch.is_tensor(z) else z
     E = E.numpy() if torch.is_tensor(E) else E

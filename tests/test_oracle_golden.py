@@ -36,6 +36,19 @@ def test_vq_ragged_and_ties():
     assert np.array_equal(O.vq_get_emb(torch.tensor([9]), E).numpy(), g["get_emb_9"])
 
 
+@pytest.mark.parametrize("K,D", [(128, 256), (512, 256)])
+@pytest.mark.parametrize("kind", ["mid", "bignorm"])
+def test_vq_oracle_vs_reference_on_near_ties(K, D, kind):
+    """Latents whose two best codes are nearly equidistant, so that the rounding order of quantizer.py:46-48 decides
+    (the reference itself leaves the exact minimum on some of these rows).  The fixture must not be vacuous."""
+    g = load_golden("vq_near")
+    z, E = synth.vq_near_tie_case(K, D, 4096, kind, seed=0)
+    assert int(g[f"near_{K}_{D}_{kind}"]) > 0 and int(g[f"ref_off_exact_{K}_{D}_{kind}"]) > 0
+    idx, _ = O.vq_forward(z, E)
+    n_diff = check_vq_rows(z, E, idx[:, 0].numpy(), g[f"idx_{K}_{D}_{kind}"])
+    print(f"K={K} {kind}: {int(g[f'near_{K}_{D}_{kind}'])} near-tie rows, oracle differs from the reference on {n_diff}")
+
+
 def test_pointnet_oracle_vs_reference():
     g = load_golden("pointnet")
     sd = synth.gennet_state_dict(0, with_prior=False)

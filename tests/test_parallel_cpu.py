@@ -192,8 +192,8 @@ def test_cpu_tensors_are_refused_everywhere():
 
 
 def test_mano_file_reader_builds_arrays_and_refuses_code(tmp_path):
-    """A synthetic pickle with the class layout of the official MANO files: chumpy
-    objects are replaced by inert stand-ins, anything else is refused unexecuted."""
+    """A synthetic pickle with the class layout of the official MANO files: the reader takes the arrays out of the
+    chumpy and scipy records without importing or calling anything the file names, and refuses every other name."""
     from dvq_hip import mano_io
     ch = types.ModuleType("chumpy"); chch = types.ModuleType("chumpy.ch"); chre = types.ModuleType("chumpy.reordering")
 
@@ -216,6 +216,7 @@ def test_mano_file_reader_builds_arrays_and_refuses_code(tmp_path):
         d = synth.mano_model_data(0)
         full = np.arange(778 * 3 * 12, dtype=np.float64).reshape(778, 3, 12)
         blob = dict(d)
+        blob_plain = dict(d)
         blob["v_template"] = Ch(d["v_template"])
         blob["shapedirs"] = Select(Ch(full), np.arange(778 * 3 * 12).reshape(778, 3, 12)[:, :, :10].ravel(), (778, 3, 10))
         path = tmp_path / "MANO_RIGHT.pkl"
@@ -232,8 +233,24 @@ def test_mano_file_reader_builds_arrays_and_refuses_code(tmp_path):
     np.testing.assert_array_equal(mano_io.to_np(out["weights"]), d["weights"].astype(np.float32))
     evil = tmp_path / "MANO_LEFT.pkl"
     evil.write_bytes(pickle.dumps({"v_template": os.getcwd}, protocol=2))
-    with pytest.raises(pickle.UnpicklingError):
+    with pytest.raises(mano_io.ModelFileError):
         mano_io.read_model_file(str(evil))
+
+    class Runs:                                    # a file that asks for a call when it is loaded
+        def __reduce__(self):
+            return (os.mkdir, (str(tmp_path / "made_by_the_file"),))
+    for proto in (2, 4):
+        evil.write_bytes(pickle.dumps(dict(blob_plain, v_template=Runs()), protocol=proto))
+        with pytest.raises(mano_io.ModelFileError):
+            mano_io.read_model_file(str(evil))
+        assert not (tmp_path / "made_by_the_file").exists()      # recorded as a tag, never called
+    # every protocol Python 3 writes holds the same arrays
+    for proto in (2, 3, 4):
+        path_p = tmp_path / f"plain{proto}.pkl"
+        path_p.write_bytes(pickle.dumps(blob_plain, protocol=proto))
+        out_p = mano_io.read_model_file(str(path_p))
+        for k in mano_io.FIELDS:
+            np.testing.assert_array_equal(mano_io.to_np(out_p[k], np.float64), mano_io.to_np(d[k], np.float64))
     import mano
     m = mano.load(str(path), use_pca=True, num_pca_comps=45, batch_size=1, flat_hand_mean=True)
     assert m.is_rhand and m.v_template.shape == (778, 3)
