@@ -204,6 +204,16 @@ def mano_model_data(seed: int = 0) -> Dict[str, np.ndarray]:
                 kintree_table=kintree, f=faces)
 
 
+def closed_hand_faces(seed: int = 0) -> np.ndarray:
+    """A face set shaped like the reference's closed hand mesh (models/mano/closed_mano_faces.pkl, read by
+    gen_HDMO_TTA.py:61-62): the model's own 1538 triangles followed by 14 that fan over a loop of 16 vertices (in the
+    official file: the open wrist), (1552, 3) int64.  The loop here is 16 arbitrary distinct vertices."""
+    f = mano_model_data(seed)["f"].astype(np.int64)
+    loop = _rng(seed, "wrist_loop").choice(N_VERTS, size=16, replace=False)
+    fan = [[loop[0], loop[i], loop[i + 1]] for i in range(1, 15)]          # a 16-gon takes 14 triangles
+    return np.concatenate([f, np.asarray(fan, dtype=np.int64)])
+
+
 def mano_state_dict(seed: int = 0, batch_size: int = 1, num_pca_comps: int = 45, flat_hand_mean: bool = True,
                     prefix: str = "", data=None) -> "OrderedDict[str, torch.Tensor]":
     """The 14 tensors MANO(...) registers (mano/model.py:170-276), built from

@@ -56,5 +56,10 @@ class VectorQuantizer(nn.Module):
         return loss, z_q, perplexity, min_encodings, idx
 
     def get_emb(self, min_encoding_indices, dim):
+        """Rows of the codebook, [n, dim].  An index outside the codebook raises (the reference's one-hot scatter_
+        fails there, quantizer.py:70-72); the check reads the indices back, which this call -- not used inside
+        gen() -- can afford."""
         idx = min_encoding_indices.reshape(-1).to(torch.int64).contiguous()
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= self.n_e):
+            raise RuntimeError(f"get_emb: index out of range for a codebook of {self.n_e} rows")
         return ops.vq_gather(idx, self.embedding.weight.detach()).view(-1, dim)

@@ -69,7 +69,10 @@ int dvq_vq_argmin_prepared(const void* z, const void* E, int64_t n, int K, int D
  * a DVQ_VQ_STATIC_WORKSPACE_BYTES array inside the library, one copy per GPU, held until the process ends; the call
  * allocates and frees nothing.  Codebooks with dvq_vq_workspace_bytes(K, D, dtype) above that size are rejected with
  * DVQ_EINVAL (K=8192 x D=256 fits in both dtypes).  Same results as dvq_vq_argmin.  All calls on one GPU share the
- * array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe. */
+ * array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe.
+ * Under stream capture: the first call on a device looks the array's address up (hipGetSymbolAddress) and the first
+ * call that reaches a kernel variant raises its dynamic-LDS limit (hipFuncSetAttribute); neither belongs in a capture,
+ * so make one call with the same (K, D, dtype) and a row count of the same order on that device before capturing. */
 #define DVQ_VQ_STATIC_WORKSPACE_BYTES (9u << 20)
 int dvq_vq_argmin_static(const void* z, const void* E, int64_t n, int K, int D, int dtype,
                          int64_t* idx_out, void* zq_out, void* stream);

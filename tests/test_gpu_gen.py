@@ -430,3 +430,43 @@ def test_training_mode_and_cpu_are_refused():
     enc_cpu = PointNetEncoder(channel=3).eval()
     with pytest.raises(RuntimeError):
         enc_cpu(torch.zeros(1, 3, 10))               # CPU tensors: no fallback
+
+
+def test_get_emb_vs_reference_golden():
+    """VectorQuantizer.get_emb / VQVAE.get_embbeding (quantizer.py:68-75, VQVAE.py:49-53) called directly: the
+    reference's own output for index 9 (its only supported call size), and the batched form row by row."""
+    from network.VQVAE import VQVAE
+    from network.vqvae.quantizer import VectorQuantizer
+    g = load_golden("vq")
+    _, E = synth.vq_case(128, 256, 37, "A", seed=3)
+    E[5] = E[77]                                                   # as the fixture was captured
+    vq = VectorQuantizer(128, 256, 0.25, 1).to(DEV).eval()
+    vq.embedding.weight.data.copy_(E)
+    e = vq.get_emb(torch.tensor([9], device=DEV), 256)
+    assert e.shape == (1, 256) and e.dtype == torch.float32
+    assert np.array_equal(e.cpu().numpy(), g["get_emb_9"])
+    wrap = VQVAE(h_dim=128, res_h_dim=32, n_res_layers=2, n_embeddings=128, embedding_dim=256, beta=0.25, a=1).to(DEV).eval()
+    wrap.vector_quantization.embedding.weight.data.copy_(E)
+    assert np.array_equal(wrap.get_embbeding(torch.tensor([9], device=DEV), 256).cpu().numpy(), g["get_emb_9"])
+    idx = torch.tensor([0, 127, 9, 9, 5, 77], device=DEV)
+    rows = vq.get_emb(idx, 256)
+    assert torch.equal(rows.cpu(), E[idx.cpu()])
+    assert torch.equal(rows.cpu(), O.vq_get_emb(idx.cpu(), E))
+    with pytest.raises(RuntimeError):
+        vq.get_emb(torch.tensor([128], device=DEV), 256)           # out of range: an error, as the reference's scatter_
+
+
+def test_gen_byid_decodes_the_zero_latent():
+    """GenNet.gen_byid (gen_net.py:41-75) samples the prior for the given object code but decodes an all-zero latent
+    and returns a zero position: the result does not depend on the code or the draw."""
+    model, _ = build()
+    sd = synth.gennet_state_dict(0, with_prior=True)
+    want = O.decoder_mlp(torch.zeros(1, 2560), sd, "decoder.")
+    recon, pos = model.gen_byid(torch.tensor([17], device=DEV))
+    assert recon.shape == (1, 55) and pos.shape == (1, 6) and float(pos.abs().max()) == 0.0
+    assert rel_err(recon, want) <= 1e-5
+    again, _ = model.gen_byid(torch.tensor([101], device=DEV))
+    assert torch.equal(again, recon)
+    many, pos_many = model.gen_byid(torch.tensor([3, 4, 5], device=DEV))
+    assert many.shape == (3, 55) and pos_many.shape == (3, 6)
+    assert torch.equal(many, recon.expand(3, -1))

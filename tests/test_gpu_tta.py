@@ -118,6 +118,36 @@ def test_contact_gradient_matches_oracle(dev, hand):
     assert torch.equal(gv3, got["grad_verts"])
 
 
+def test_contact_gradient_with_the_closed_hand_mesh(dev, hand):
+    """The reference takes its vertex normals from a closed hand mesh of 1552 faces, not from the model's own 1538
+    (gen_HDMO_TTA.py:61-62: closed_mano_faces.pkl = the model's faces + 14 over the wrist).  A face set handed to
+    GraspRefiner(rh, faces=...) must be the one the kernel uses: same scene, a synthetic face set of that shape,
+    against the oracle with the same faces.  (Normals / nearest neighbour themselves: parity unpinned, as stated in
+    oracle/tta_oracle.py.)"""
+    from dvq_hip.tta import GraspRefiner
+    from oracle import tta_oracle as T
+    rh, sd = hand
+    closed = torch.from_numpy(synth.closed_hand_faces(0))
+    assert closed.shape == (1552, 3) and torch.equal(closed[:1538], sd["faces_tensor"])
+    param, obj, obj_pc = _scene(sd, 3, seed=23)
+    ref = T.loss_and_grad(sd, closed, obj, param, CONTACT_VERTS)
+    ref_open = T.loss_and_grad(sd, sd["faces_tensor"], obj, param, CONTACT_VERTS)
+    got = GraspRefiner(rh, faces=closed).loss_and_grad(obj_pc.to(dev), param.to(dev))
+    assert int(ref["interior"].sum()) > 100
+    assert torch.allclose(got["losses"][:, 0].cpu(), ref["penetr"].detach(), rtol=1e-5)
+    assert torch.allclose(got["losses"][:, 1].cpu(), ref["contact"].detach(), rtol=1e-5)
+    assert _relmax(got["grad_verts"].cpu(), ref["grad_verts"]) < 1e-5
+    assert _relmax(got["grad_param"].cpu(), ref["grad_param"]) < 5e-5
+    # the extra faces matter: the 16 loop vertices get other normals, so the interior mask and the gradient move
+    assert not torch.equal(ref["interior"], ref_open["interior"]) or _relmax(ref["grad_verts"], ref_open["grad_verts"]) > 1e-4
+    assert _relmax(got["grad_verts"].cpu(), ref_open["grad_verts"]) > 1e-6
+    # the whole loop on the closed mesh (small steps, masks fixed): GPU trajectory vs the oracle's SGD
+    iters, lr = 8, 1e-8
+    p_ref, _ = T.refine(sd, closed, obj, param, CONTACT_VERTS, iters=iters, lr=lr)
+    out = GraspRefiner(rh, faces=closed, lr=lr).refine(obj_pc.to(dev), param.to(dev), iters=iters)
+    assert _relmax(out["recon_param"].cpu() - param, p_ref - param) < 2e-4
+
+
 def test_exact_distance_ties_go_to_the_lowest_vertex_id(dev, hand):
     """Two vertices at one position, one inside the contact set and one outside: the nearest-vertex index of a point
     next to them is the LOWER id whichever part holds it (the kernel searches the contact set first; the rule is that

@@ -109,6 +109,8 @@ def test_closed_hand_faces(real):
     _, counts = np.unique(edges, axis=0, return_counts=True)
     assert (counts == 2).all()
     open_f = mano_io.to_np(real["f"], np.int64)
+    assert np.array_equal(f[:1538], open_f)                           # the model's faces, then 14 over the wrist loop
+    assert len(set(f[1538:].ravel().tolist())) == 16
     e2 = np.sort(np.concatenate([open_f[:, [0, 1]], open_f[:, [1, 2]], open_f[:, [2, 0]]]), axis=1)
     _, c2 = np.unique(e2, axis=0, return_counts=True)
     assert (c2 == 1).sum() > 0                                        # the model's own mesh is open at the wrist
