@@ -32,6 +32,10 @@ PMC_TRAFFIC_BYTES = 2.173e8                     # encoder trunk, 4096 x 3000 x C
 PEAK_HBM_GBS = 8000.0                           # HBM3E spec; a bare 16-B-per-lane read of 0.5 GB reaches 5.0-5.4 TB/s here
 PEAK_L2_LDS_GBS = 17500.0                       # L2 -> LDS gather rate the part sustains (16.8-18.8 TB/s measured)
 FLOP_PER_POINT = {3: 2 * (3 * 64 + 64 * 128 + 128 * 1024), 4: 2 * (4 * 64 + 64 * 128 + 128 * 1024)}
+# one hand through the MANO layer in its dense form (DVQ-VAE-2/MANO-master/mano/lbs.py:33-120): PCA 45x45, pose blend
+# shapes 135 x 2334, skinning weights x transforms 778 x 16 x 16, transform x vertex 778 x 16, kinematic chain 15 x 4x4x4
+MANO_FLOP_PER_HAND = 2 * (45 * 45 + 135 * 2334 + 778 * 16 * 16 + 778 * 16 + 15 * 64)
+MANO_BYTES_PER_HAND = 61 * 4 + 778 * 3 * 4 + 16 * 3 * 4
 
 
 def timed_steps(fn, steps, warmup, device, barrier, kernel_timers=False, finish=None):
@@ -55,6 +59,46 @@ def timed_steps(fn, steps, warmup, device, barrier, kernel_timers=False, finish=
     return time.perf_counter() - t0
 
 
+def encoder_roofline(N, dtype_name, traffic_note=True):
+    """`roofline` object for the object-encoder trunk launches recorded by ops.TIMERS since the last enable_timers."""
+    ks = kernel_stats(f"pointnet_mlp_max[C=4,N={N}]")
+    if ks is None:
+        return None
+    avg_ms, launches, (kb, kc, kn), name, alone_ms = ks
+    flops = float(kb) * kn * FLOP_PER_POINT[kc]
+    ach = flops / avg_ms / 1e9
+    peak = PEAK_TFLOPS[dtype_name]
+    # HBM bytes per launch from the FETCH_SIZE (x2, the gfx950 correction for 16-B-per-lane streams) and WRITE_SIZE
+    # counters: NOT measured by this run -- a constant from separate rocprofv3 --pmc passes over the same kernel and
+    # shape (profiles/r2c_pmc_fetch_write.txt); only valid for that configuration
+    traffic = PMC_TRAFFIC_BYTES if (kb, kc, kn, dtype_name) == (4096, 4, 3000, "bf16") else None
+    out = {"bound": "mfma", "kernel": name + (" (v_mfma_f32_16x16x32_bf16)" if dtype_name == "bf16" else " (v_mfma_f32_32x32x2_f32)"),
+           "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+           "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches, "flop_per_launch": flops}
+    if traffic is not None:
+        out["traffic_note"] = ("HBM bytes per launch from separate PMC passes (profiles/r2c_pmc_fetch_write.txt), not from this "
+                               "run; algorithmic bytes 2.134e8")
+    return out
+
+
+def mano_roofline():
+    """The MANO layer's launches of the timed steps (two per step: inside gen() and at the call site).  Its arithmetic
+    intensity (about 110 FLOP per byte of parameters in and vertices out) is above the fp32 ridge, so the bound it is
+    priced against is the fp32 matrix peak; the HBM figure is given beside it."""
+    ks = kernel_stats("mano_lbs")
+    if ks is None or ks[3] != "mano_lbs":
+        return None
+    avg_ms, launches, (kb,), name, _ = ks
+    flops = float(kb) * MANO_FLOP_PER_HAND
+    ach = flops / avg_ms / 1e9
+    nbytes = float(kb) * MANO_BYTES_PER_HAND
+    return {"bound": "mfma", "kernel": "mano_lbs (v_mfma_f32_16x16x4_f32 pose blend shapes + table skinning)", "achieved": round(ach, 2),
+            "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 5), "launches_timed": launches, "flop_per_launch": flops, "hands_per_launch": kb,
+            "hbm_gbs": round(nbytes / avg_ms / 1e6, 1), "frac_hbm_peak": round(nbytes / avg_ms / 1e6 / PEAK_HBM_GBS, 4),
+            "note": "dense-form FLOPs (the kernel skips the zero skinning weights: 1-6 of 16 joints per vertex)"}
+
+
 def kernel_stats(name_prefix):
     """(avg ms, launches, work tuple) over launches recorded by ops.TIMERS."""
     best = None
@@ -68,10 +112,13 @@ def kernel_stats(name_prefix):
     return best
 
 
-def near_ties(z, E, idx, ulps=4.0):
+def near_ties(z, E, idx, ulps=None):
     """On a sample of rows (z, E as the kernel saw them, widened to fp64): how many have their two nearest codes closer
-    than `ulps` fp32 ulps of |z|^2 + max|E|^2 (where the reference's own fp32 rounding decides the winner), and how
-    many of the kernel's choices are not the exact fp64 nearest code / not even within that tolerance of it."""
+    than `ulps` fp32 spacings of |z|^2 + max|E|^2 (where the reference's own fp32 rounding decides the winner; default
+    max(4, sqrt(D)), the rule of the parity tests), and how many of the kernel's choices are not the exact fp64 nearest
+    code / not even within that tolerance of it."""
+    if ulps is None:
+        ulps = max(4.0, float(E.shape[1]) ** 0.5)
     z64, E64 = z.double(), E.double()
     d = (z64 * z64).sum(1, keepdim=True) + (E64 * E64).sum(1) - 2.0 * z64 @ E64.t()
     top = torch.topk(d, 2, dim=1, largest=False)
@@ -320,7 +367,8 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ks = kernel_stats(f"pointnet_mlp_max[C=4,N={N}]")
+    roof = encoder_roofline(N, args.dtype)
+    roof_mano = mano_roofline()
     ops.enable_timers(False)
 
     # The collective by itself: the same all-gather of one step's vertices with nothing beside it (in the timed
@@ -360,25 +408,10 @@ def main():
         }
         if gather_alone is not None:
             result["all_gather"] = gather_alone
-        if ks is not None:
-            avg_ms, launches, (kb, kc, kn), name, alone_ms = ks
-            flops = float(kb) * kn * FLOP_PER_POINT[kc]
-            ach = flops / avg_ms / 1e9
-            # HBM bytes per launch from the FETCH_SIZE (x2, the gfx950 correction for 16-B-per-lane streams) and
-            # WRITE_SIZE counters: NOT measured by this run -- a constant from separate rocprofv3 --pmc passes over the
-            # same kernel and shape (profiles/r2c_pmc_fetch_write.txt); only valid for that configuration
-            traffic = PMC_TRAFFIC_BYTES if (kb, kc, kn, args.dtype) == (4096, 4, 3000, "bf16") else None
-            result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1),
-                                  "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
-                                  "traffic_note": "HBM bytes per launch from separate PMC passes (profiles/r2c_pmc_fetch_write.txt), "
-                                                  "not from this run; algorithmic bytes 2.134e8",
-                                  "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
-                                  # launches issued on the caller's own stream (all of them since generation became
-                                  # single-stream; earlier builds ran half of them beside the prior on a second stream)
-                                  "avg_launch_ms_uncontended": None if alone_ms is None else round(alone_ms, 4),
-                                  "frac_uncontended": None if alone_ms is None else round(flops / alone_ms / 1e9 / PEAK_TFLOPS[args.dtype], 4),
-                                  "flop_per_launch": flops}
+        if roof is not None:
+            result["roofline"] = roof
+        if roof_mano is not None:
+            result["roofline_mano"] = roof_mano
 
     if not args.no_extras and world == 1:
         # variants of the same step, the VQ microbench and the CPU baseline (rank 0, N=1 only)
@@ -392,8 +425,16 @@ def main():
         el = timed_steps(lambda: step("forced"), 2, 1, device, barrier)
         oname = 'fp32' if args.dtype == 'bf16' else 'bf16'
         variants[f"{oname}_prior_forced"] = round(B * 2 / el, 1)
-        el = timed_steps(lambda: step("sampled"), 2, 1, device, barrier)
-        variants[f"{oname}_prior_sampled"] = round(B * 2 / el, 1)
+        # the other precision as a leg of its own: the same step, the same number of timed steps and warm-up steps, its
+        # own per-launch events (the reference's arithmetic is fp32; the headline follows the configuration's bf16)
+        el = timed_steps(lambda: step("sampled"), args.steps, args.warmup, device, barrier, kernel_timers=True)
+        roof_o = encoder_roofline(N, oname)
+        ops.enable_timers(False)
+        variants[f"{oname}_prior_sampled"] = round(B * args.steps / el, 1)
+        result[f"{oname}_leg"] = {"value": round(B * args.steps / el, 1), "unit": "grasps/s", "ms_per_step": round(el / args.steps * 1e3, 3),
+                                  "steps": args.steps, "warmup": args.warmup, "dtype": oname, "prior": "sampled"}
+        if roof_o is not None:
+            result[f"roofline_{oname}"] = roof_o
         dvq_hip.set_compute_dtype(gen.model, tdtype)
         # The random-init object codebook sends every synthetic cloud to ONE class, the best case for the prior's
         # per-class table reads.  Trained-like case: the object codebook set to the features of 128 of the batch's own
