@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One line per launch of the dvq matrix-core kernels from a rocprofv3 --pmc counter_collection.csv:
-    python tools/mfma_pmc_summary.py <counter_collection.csv>
+    python tools/mfma_pmc_summary.py <counter_collection.csv> [kernel-name substring, default "dvq::"]
 duration (us) from the dispatch timestamps; clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; matrix-pipe busy share =
 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); SQ_* wave counters in quad-cycles, shown as shares of
 SQ_WAVE_CYCLES."""
@@ -8,11 +8,12 @@ import collections
 import csv
 import sys
 
+want = sys.argv[2] if len(sys.argv) > 2 else "dvq::"
 rows = collections.OrderedDict()
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         name = r["Kernel_Name"]
-        if "dvq::" not in name or "pack" in name:
+        if want not in name or "pack" in name:
             continue
         d = rows.setdefault(int(r["Dispatch_Id"]), {"name": name.split("(")[0].replace("void ", ""), "grid": r["Grid_Size"],
                                                      "t": (int(r["Start_Timestamp"]), int(r["End_Timestamp"]))})
