@@ -43,7 +43,7 @@ typedef f32x4 f32x4u __attribute__((aligned(4)));   // four floats at any 4-byte
 template <bool TABLE, int WAVES, bool LANES>
 __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
     const float* __restrict__ global_orient, const float* __restrict__ hand_pose, const float* __restrict__ transl,
-    int B, int V, int ncomp, const float* __restrict__ v_shaped, const float* __restrict__ joints,
+    int ld_go, int ld_hp, int ld_tr, int B, int V, int ncomp, const float* __restrict__ v_shaped, const float* __restrict__ joints,
     const float* __restrict__ posedirs, const float* __restrict__ weights, const float* __restrict__ comps,
     const float* __restrict__ pose_mean, const int* __restrict__ parents, const unsigned char* __restrict__ skin_joints,
     const float* __restrict__ skin_weights, const float* __restrict__ pd_lanes, float* __restrict__ verts_out,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
 
     // Everything the two serial phases read goes to LDS in one round of coalesced loads: fetched where it is used
     // (45 dependent steps of the PCA product, 16 of the chain) each load would cost a trip to L2.
-    for (int i = tid; i < nh * ncomp; i += THREADS) sHP[i / ncomp][i % ncomp] = hand_pose[(int64_t)b0 * ncomp + i];
+    for (int i = tid; i < nh * ncomp; i += THREADS) sHP[i / ncomp][i % ncomp] = hand_pose[(int64_t)(b0 + i / ncomp) * ld_hp + i % ncomp];
     for (int i = tid; i < ncomp * 45; i += THREADS) sComps[i] = comps[i];
     if (tid < kJ * 3) sJ[tid] = joints[tid];
     if (tid < kJ) sPar[tid] = parents[tid];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
             for (int c = 0; c < 3; ++c) {
                 float v;
                 if (j == 0) {
-                    v = global_orient[b * 3 + c];
+                    v = global_orient ? global_orient[(int64_t)b * ld_go + c] : 0.f;
                 } else {
                     const int col = 3 * (j - 1) + c;
                     v = 0.f;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
                 }
             if (j == 0) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) sTr[hnd][c] = transl ? transl[b * 3 + c] : 0.f;
+                for (int c = 0; c < 3; ++c) sTr[hnd][c] = transl ? transl[(int64_t)b * ld_tr + c] : 0.f;
             }
         } else if (j > 0) {   // hands past the end of the batch: finite operands for the matrix product
 #pragma unroll
@@ -422,13 +422,15 @@ __global__ __launch_bounds__(WAVES * 64) void mano_lbs_kernel(
 
 using namespace dvq;
 
-extern "C" int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float* transl, int B,
-                            const DvqManoConsts* m, float* verts_out, float* joints_out, float* full_pose_out, float* v_posed_out,
-                            void* stream) {
+extern "C" int dvq_mano_lbs_rows(const float* global_orient, int64_t ld_go, const float* hand_pose, int64_t ld_hp, const float* transl,
+                                 int64_t ld_tr, int B, const DvqManoConsts* m, float* verts_out, float* joints_out,
+                                 float* full_pose_out, float* v_posed_out, void* stream) {
     if (B < 0) return fail(DVQ_EINVAL, "mano: negative batch");
     if (B == 0) return DVQ_OK;
-    if (!m || !global_orient || !hand_pose || !verts_out) return fail(DVQ_EINVAL, "mano: null pointer");
+    if (!m || !hand_pose || !verts_out) return fail(DVQ_EINVAL, "mano: null pointer");
     if (m->n_verts < 1 || m->n_comps < 1 || m->n_comps > 45) return fail(DVQ_EINVAL, "mano: bad n_verts/n_comps (%d, %d)", m->n_verts, m->n_comps);
+    if (ld_hp < m->n_comps || (global_orient && ld_go < 3) || (transl && ld_tr < 3) || ld_go > INT32_MAX || ld_hp > INT32_MAX || ld_tr > INT32_MAX)
+        return fail(DVQ_EINVAL, "mano: a row stride is shorter than its row (or beyond 2^31)");
     if (!m->v_shaped || !m->joints || !m->posedirs || !m->lbs_weights || !m->components || !m->pose_mean || !m->parents)
         return fail(DVQ_EINVAL, "mano: null constant table");
     const bool table = m->skin_joints != nullptr;
@@ -437,17 +439,29 @@ extern "C" int dvq_mano_lbs(const float* global_orient, const float* hand_pose, 
     if (((uintptr_t)m->lbs_weights & 15) != 0) return fail(DVQ_EINVAL, "mano: lbs_weights must be 16-byte aligned");
     if (((uintptr_t)m->posedirs_lanes & 3) != 0) return fail(DVQ_EINVAL, "mano: posedirs_lanes must be 4-byte aligned");
     const int grid = (B + kMH - 1) / kMH;
+    const int lg = (int)ld_go, lh = (int)ld_hp, lt = (int)ld_tr;
     if (table && m->posedirs_lanes)
-        hipLaunchKernelGGL((mano_lbs_kernel<true, 8, true>), dim3(grid), dim3(512), 0, as_stream(stream), global_orient, hand_pose, transl, B,
-                           m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
-                           m->parents, m->skin_joints, m->skin_weights, m->posedirs_lanes, verts_out, joints_out, full_pose_out, v_posed_out);
+        hipLaunchKernelGGL((mano_lbs_kernel<true, 8, true>), dim3(grid), dim3(512), 0, as_stream(stream), global_orient, hand_pose, transl,
+                           lg, lh, lt, B, m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components,
+                           m->pose_mean, m->parents, m->skin_joints, m->skin_weights, m->posedirs_lanes, verts_out, joints_out,
+                           full_pose_out, v_posed_out);
     else if (table)
-        hipLaunchKernelGGL((mano_lbs_kernel<true, 8, false>), dim3(grid), dim3(512), 0, as_stream(stream), global_orient, hand_pose, transl, B,
-                           m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
-                           m->parents, m->skin_joints, m->skin_weights, nullptr, verts_out, joints_out, full_pose_out, v_posed_out);
+        hipLaunchKernelGGL((mano_lbs_kernel<true, 8, false>), dim3(grid), dim3(512), 0, as_stream(stream), global_orient, hand_pose, transl,
+                           lg, lh, lt, B, m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components,
+                           m->pose_mean, m->parents, m->skin_joints, m->skin_weights, nullptr, verts_out, joints_out, full_pose_out,
+                           v_posed_out);
     else
-        hipLaunchKernelGGL((mano_lbs_kernel<false, 4, false>), dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose, transl, B,
-                           m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights, m->components, m->pose_mean,
-                           m->parents, nullptr, nullptr, nullptr, verts_out, joints_out, full_pose_out, v_posed_out);
+        hipLaunchKernelGGL((mano_lbs_kernel<false, 4, false>), dim3(grid), dim3(kManoThreads), 0, as_stream(stream), global_orient, hand_pose,
+                           transl, lg, lh, lt, B, m->n_verts, m->n_comps, m->v_shaped, m->joints, m->posedirs, m->lbs_weights,
+                           m->components, m->pose_mean, m->parents, nullptr, nullptr, nullptr, verts_out, joints_out, full_pose_out,
+                           v_posed_out);
     return check_launch("mano_lbs");
+}
+
+extern "C" int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float* transl, int B,
+                            const DvqManoConsts* m, float* verts_out, float* joints_out, float* full_pose_out, float* v_posed_out,
+                            void* stream) {
+    if (B > 0 && !global_orient) return fail(DVQ_EINVAL, "mano: null pointer");
+    return dvq_mano_lbs_rows(global_orient, 3, hand_pose, m ? m->n_comps : 0, transl, 3, B, m, verts_out, joints_out, full_pose_out,
+                             v_posed_out, stream);
 }

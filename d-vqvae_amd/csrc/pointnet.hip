@@ -86,13 +86,15 @@ __global__ void pn_pack_w3_kernel(const float* __restrict__ a3, uint4* __restric
 // conv1 (VALU) + conv2 (MFMA) for one tile of 32 points: lane (r,h) owns point `n`.
 // Leaves relu(conv2) in `Xf_np` (64 values) in the k order conv3 consumes.
 template <int DT, int C>
-__device__ __forceinline__ void pn_point_tile(const float* __restrict__ xb_, int N, int n, bool has_trans, const float (&T)[9],
+__device__ __forceinline__ void pn_point_tile(const float* __restrict__ xb_, int N, int pm, int n, bool has_trans, const float (&T)[9],
                                               const float* a1s, const float* c1s, const char* a2s, const float* c2s,
                                               int lane, int h, float (&Xf_np)[64]) {
     const float* xb = xb_;
     float p[4];
+    // a cloud is C*N floats either way: channel-major [C][N] (the reference's layout) or point-major [N][C]
+    const int sc = pm ? 1 : N, sn = pm ? C : 1;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) p[c] = c < C ? xb[(int64_t)c * N + n] : 0.f;
+    for (int c = 0; c < 4; ++c) p[c] = c < C ? xb[(int64_t)c * sc + (int64_t)n * sn] : 0.f;
     if (has_trans) {  // xyz' = xyz * T  (pointnet_encoder.py:146)
         const float q0 = p[0], q1 = p[1], q2 = p[2];
 #pragma unroll
@@ -178,7 +180,7 @@ __device__ __forceinline__ void pn_body(
     const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
     const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
     const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb,
-    int block_id) {
+    int block_id, int pm) {
     typedef PnCfg<DT> Cfg;
     constexpr int NP = Cfg::NP;
     constexpr int STAGE_BYTES = Cfg::CPS * Cfg::UPC * 1024;
@@ -259,7 +261,7 @@ __device__ __forceinline__ void pn_body(
         if (np < nv) {                                                                                            \
             int n = (tile0 + np * wpc) * 32 + r;                                                                  \
             if (n >= N) n = N - 1; /* duplicate the last point: a duplicate cannot change a max */                \
-            pn_point_tile<DT, C>(xb, N, n, has_trans, T, a1s, c1s, a2s, c2s, lane, h, Xf[np]);                    \
+            pn_point_tile<DT, C>(xb, N, pm, n, has_trans, T, a1s, c1s, a2s, c2s, lane, h, Xf[np]);                    \
         }                                                                                                         \
     }
             DVQ_PN_TILE(0) DVQ_PN_TILE(1) DVQ_PN_TILE(2) DVQ_PN_TILE(3)
@@ -334,14 +336,14 @@ template <int DT, int C>
 __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp_max_kernel(
     const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
     const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
-    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb) {
-    pn_body<DT, C>(x, trans, N, a1, c1, a2, c2, w3p, c3, relu3, feat, B, cpb, blockIdx.x);
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb, int pm) {
+    pn_body<DT, C>(x, trans, N, a1, c1, a2, c2, w3p, c3, relu3, feat, B, cpb, blockIdx.x, pm);
 }
 template <int DT, int C>
 __global__ __launch_bounds__(kPnThreads, PnCfg<DT>::MIN_WAVES) void pointnet_mlp_max_grouped_kernel(PnGroupsDev g) {
     const int k = pn_group_of(g, blockIdx.x);
     pn_body<DT, C>(g.x[k], g.trans[k], g.N[k], g.a1[k], g.c1[k], g.a2[k], g.c2[k], g.w3p[k], g.c3[k], g.relu3[k], g.feat[k],
-                   g.B[k], g.cpb[k], blockIdx.x - g.block_start[k]);
+                   g.B[k], g.cpb[k], blockIdx.x - g.block_start[k], 0);
 }
 
 // ------------------------------------------------------------------ bf16, 16x16x32 tiles
@@ -379,12 +381,13 @@ __global__ void pn_pack_w3_16_kernel(const float* __restrict__ a3, uint4* __rest
 
 // conv1 + conv2 for one tile of 16 points; leaves relu(conv2) as the four conv3 A fragments of the tile.
 template <int C>
-__device__ __forceinline__ void pn_point_tile16(const float* __restrict__ xb, int N, int n, bool has_trans, const float (&T)[9],
+__device__ __forceinline__ void pn_point_tile16(const float* __restrict__ xb, int N, int pm, int n, bool has_trans, const float (&T)[9],
                                                 const float* a1s, const float* c1s, const char* a2s, const float* c2s,
                                                 int lane, int q, bf16x8 (&X)[4]) {
     float p[4];
+    const int sc = pm ? 1 : N, sn = pm ? C : 1;   // channel-major [C][N] or point-major [N][C]
 #pragma unroll
-    for (int c = 0; c < 4; ++c) p[c] = c < C ? xb[(int64_t)c * N + n] : 0.f;
+    for (int c = 0; c < 4; ++c) p[c] = c < C ? xb[(int64_t)c * sc + (int64_t)n * sn] : 0.f;
     if (has_trans) {  // xyz' = xyz * T  (pointnet_encoder.py:146)
         const float q0 = p[0], q1 = p[1], q2 = p[2];
 #pragma unroll
@@ -440,7 +443,7 @@ __device__ __forceinline__ void pn16_body(
     const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
     const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
     const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb,
-    int block_id) {
+    int block_id, int pm) {
     constexpr int NP = kPnNP16;
     constexpr int STAGE_BYTES = kPnCPS16 * kPnUPC16 * 1024;
     constexpr int N_STAGES = kCt16 / kPnCPS16;
@@ -512,7 +515,7 @@ __device__ __forceinline__ void pn16_body(
     if (np < nv) {                                                                                     \
         int n = (tile0 + np * wpc) * 16 + c;                                                           \
         if (n >= N) n = N - 1; /* duplicate the last point: a duplicate cannot change a max */         \
-        pn_point_tile16<C>(xb, N, n, has_trans, T, a1s, c1s, a2s, c2s, lane, q, X[np]);                \
+        pn_point_tile16<C>(xb, N, pm, n, has_trans, T, a1s, c1s, a2s, c2s, lane, q, X[np]);                \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     }
         DVQ_PN_TILE16(0) DVQ_PN_TILE16(1) DVQ_PN_TILE16(2) DVQ_PN_TILE16(3)
@@ -583,14 +586,14 @@ template <int C>
 __global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ trans, int N, const float* __restrict__ a1,
     const float* __restrict__ c1, const float* __restrict__ a2, const float* __restrict__ c2,
-    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb) {
-    pn16_body<C>(x, trans, N, a1, c1, a2, c2, w3p, c3, relu3, feat, B, cpb, blockIdx.x);
+    const char* __restrict__ w3p, const float* __restrict__ c3, int relu3, float* __restrict__ feat, int B, int cpb, int pm) {
+    pn16_body<C>(x, trans, N, a1, c1, a2, c2, w3p, c3, relu3, feat, B, cpb, blockIdx.x, pm);
 }
 template <int C>
 __global__ __launch_bounds__(kPnThreads, 4) void pointnet_mlp_max_bf16_grouped_kernel(PnGroupsDev g) {
     const int k = pn_group_of(g, blockIdx.x);
     pn16_body<C>(g.x[k], g.trans[k], g.N[k], g.a1[k], g.c1[k], g.a2[k], g.c2[k], g.w3p[k], g.c3[k], g.relu3[k], g.feat[k], g.B[k],
-                 g.cpb[k], blockIdx.x - g.block_start[k]);
+                 g.cpb[k], blockIdx.x - g.block_start[k], 0);
 }
 
 template <int DT>
@@ -610,24 +613,24 @@ static size_t pn_lds_bytes16(int cpb) {
 }
 
 template <int C>
-static int pn_launch16(const float* x, const float* trans, int B, int N, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
+static int pn_launch16(const float* x, const float* trans, int B, int N, int pm, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
     auto kern = pointnet_mlp_max_bf16_kernel<C>;
     const int cpb = pn_cpb(N, kPnNP16 * 16);
     const size_t lds = pn_lds_bytes16(cpb);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "pointnet_mlp_max")) return rc;
     hipLaunchKernelGGL(kern, dim3((B + cpb - 1) / cpb), dim3(kPnThreads), lds, st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
-                       reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat, B, cpb);
+                       reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat, B, cpb, pm);
     return check_launch("pointnet_mlp_max");
 }
 
 template <int DT, int C>
-static int pn_launch(const float* x, const float* trans, int B, int N, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
+static int pn_launch(const float* x, const float* trans, int B, int N, int pm, const DvqPointMlp* w, int relu3, float* feat, hipStream_t st) {
     auto kern = pointnet_mlp_max_kernel<DT, C>;
     const int cpb = pn_cpb(N, PnCfg<DT>::NP * 32);
     const size_t lds = pn_lds_bytes<DT>(cpb);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "pointnet_mlp_max")) return rc;
     hipLaunchKernelGGL(kern, dim3((B + cpb - 1) / cpb), dim3(kPnThreads), lds, st, x, trans, N, w->a1, w->c1, w->a2, w->c2,
-                       reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat, B, cpb);
+                       reinterpret_cast<const char*>(w->w3p), w->c3, relu3, feat, B, cpb, pm);
     return check_launch("pointnet_mlp_max");
 }
 
@@ -695,8 +698,8 @@ extern "C" int dvq_pointnet_pack_w3(const float* a3, int dtype, void* w3p, void*
     return check_launch("pointnet_pack_w3");
 }
 
-extern "C" int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, int C, int N, const DvqPointMlp* w, int relu3,
-                                    int dtype, float* feat_out, void* stream) {
+extern "C" int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, int C, int N, int point_major, const DvqPointMlp* w,
+                                    int relu3, int dtype, float* feat_out, void* stream) {
     if (B < 0 || N < 1) return fail(DVQ_EINVAL, "pointnet: bad shape B=%d N=%d", B, N);
     if (C != 3 && C != 4) return fail(DVQ_EINVAL, "pointnet: C must be 3 or 4 (got %d)", C);
     if (B == 0) return DVQ_OK;
@@ -704,11 +707,12 @@ extern "C" int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, i
     if (!w->a1 || !w->c1 || !w->a2 || !w->c2 || !w->w3p || !w->c3) return fail(DVQ_EINVAL, "pointnet: null weight pointer");
     if (((uintptr_t)w->a2 & 15) || ((uintptr_t)w->w3p & 15)) return fail(DVQ_EINVAL, "pointnet: a2 and w3p must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
+    const int pm = point_major ? 1 : 0;
     if (dtype == DVQ_BF16) {
-        return C == 3 ? pn_launch16<3>(x, trans, B, N, w, relu3, feat_out, st) : pn_launch16<4>(x, trans, B, N, w, relu3, feat_out, st);
+        return C == 3 ? pn_launch16<3>(x, trans, B, N, pm, w, relu3, feat_out, st) : pn_launch16<4>(x, trans, B, N, pm, w, relu3, feat_out, st);
     } else if (dtype == DVQ_F32) {
-        return C == 3 ? pn_launch<DVQ_F32, 3>(x, trans, B, N, w, relu3, feat_out, st)
-                      : pn_launch<DVQ_F32, 4>(x, trans, B, N, w, relu3, feat_out, st);
+        return C == 3 ? pn_launch<DVQ_F32, 3>(x, trans, B, N, pm, w, relu3, feat_out, st)
+                      : pn_launch<DVQ_F32, 4>(x, trans, B, N, pm, w, relu3, feat_out, st);
     }
     return fail(DVQ_EINVAL, "pointnet: unknown dtype %d", dtype);
 }

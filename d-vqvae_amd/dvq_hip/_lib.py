@@ -73,7 +73,7 @@ SIGNATURES = {
     "dvq_vq_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "dvq_pointnet_w3_bytes": (c_size_t, [c_int]),
     "dvq_pointnet_pack_w3": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
-    "dvq_pointnet_mlp_max": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DvqPointMlp), c_int, c_int, c_void_p, c_void_p]),
+    "dvq_pointnet_mlp_max": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(DvqPointMlp), c_int, c_int, c_void_p, c_void_p]),
     "dvq_pointnet_mlp_max_grouped": (c_int, [POINTER(DvqPointGroup), c_int, c_int, c_int, c_void_p]),
     "dvq_gather_parts": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dvq_fold_bn": (c_int, [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -90,6 +90,11 @@ SIGNATURES = {
     "dvq_prior_uniforms": (c_int, [c_int64, c_int64, c_int, ctypes.c_uint64, c_void_p, c_void_p]),
     "dvq_prior_vrow": (c_int, [POINTER(DvqPriorVRow), c_int, c_int, c_void_p]),
     "dvq_prior_sample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dvq_mano_lbs_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    "dvq_assemble_param": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "dvq_prior_class_order": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dvq_unpermute_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "dvq_mano_lbs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
     "dvq_mano_lbs_backward": (c_int, [c_void_p, c_void_p, c_int, POINTER(DvqManoConsts), c_void_p, c_void_p, c_void_p, c_void_p,

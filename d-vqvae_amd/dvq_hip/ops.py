@@ -192,16 +192,27 @@ def pointnet_pack_w3(a3: torch.Tensor, dtype_code: int) -> torch.Tensor:
     return out
 
 
+def is_point_major(x: torch.Tensor) -> bool:
+    """x [B,C,N] is a view of a contiguous [B,N,C] buffer (and not also contiguous as [B,C,N])."""
+    B, C, N = x.shape
+    return x.dim() == 3 and not x.is_contiguous() and x.stride(1) == 1 and x.stride(2) == C and (B <= 1 or x.stride(0) == C * N)
+
+
 def pointnet_mlp_max(x: torch.Tensor, trans: Optional[torch.Tensor], w: dict, relu3: bool, dtype_code: int) -> torch.Tensor:
     """Shared per-point MLP C->64->128->1024 + max over points.  x [B,C,N] fp32 ->
-    [B,1024] fp32.  `w` holds the folded tensors a1,c1,a2,c2,c3 and the packed w3p."""
-    _need_gpu(x, trans, w["a1"], w["c1"], w["a2"], w["c2"], w["w3p"], w["c3"])
+    [B,1024] fp32; x is either contiguous (channel-major clouds, the reference's layout) or a permuted view of a
+    contiguous [B,N,C] buffer (point-major, e.g. a vertex array), read in place.  `w` holds the folded tensors
+    a1,c1,a2,c2,c3 and the packed w3p."""
+    pm = is_point_major(x)
+    _need_gpu(None if pm else x, trans, w["a1"], w["c1"], w["a2"], w["c2"], w["w3p"], w["c3"])
+    if pm and not x.is_cuda:
+        raise RuntimeError("dvq_hip kernels need tensors on a HIP device (got a CPU tensor); there is no CPU fallback")
     B, C, N = x.shape
     feat = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
     s = DvqPointMlp(w["a1"].data_ptr(), w["c1"].data_ptr(), w["a2"].data_ptr(), w["c2"].data_ptr(),
                     w["w3p"].data_ptr(), w["c3"].data_ptr())
     with torch.cuda.device(x.device), _timed(f"pointnet_mlp_max[C={C},N={N}]", (B, C, N), x):
-        rc = _lib.load().dvq_pointnet_mlp_max(_p(x), _p(trans), B, C, N, ctypes.byref(s), int(relu3), dtype_code,
+        rc = _lib.load().dvq_pointnet_mlp_max(_p(x), _p(trans), B, C, N, int(pm), ctypes.byref(s), int(relu3), dtype_code,
                                               _p(feat), _stream(x))
     _lib.check(rc, "dvq_pointnet_mlp_max")
     return feat
@@ -318,15 +329,80 @@ def linear_batched(xs, Ws, bs, relu: bool = False, add_identity3: bool = False, 
     return outs
 
 
+# ------------------------------------------------------------------- call-site glue
+PRIOR_ORDER_MAX_CLASSES = 1024
+
+
+def assemble_param(recon: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """[B,61] = [betas 10 | global_orient 3 | pose 45 | transl 3] from the decoder's [B,55] and the position decoder's
+    [B,6] outputs (gen_diverse_grasp_obman.py:243-247), one launch."""
+    B = recon.shape[0]
+    for t, w in ((recon, 55), (pos, 6)):
+        if not t.is_cuda or t.dtype != torch.float32 or t.shape != (B, w) or t.stride(1) != 1:
+            raise RuntimeError("assemble_param: float32 [B,55] and [B,6] tensors on a HIP device expected")
+    out = torch.empty(B, 61, dtype=torch.float32, device=recon.device)
+    with torch.cuda.device(recon.device):
+        rc = _lib.load().dvq_assemble_param(_p(recon), recon.stride(0) if B > 1 else 55, _p(pos), pos.stride(0) if B > 1 else 6, B,
+                                            _p(out), _stream(recon))
+    _lib.check(rc, "dvq_assemble_param")
+    return out
+
+
+def prior_class_order(label: torch.Tensor, u: Optional[torch.Tensor], n_classes: int, label_sorted: torch.Tensor,
+                      u_sorted: Optional[torch.Tensor], perm: torch.Tensor) -> None:
+    """Stable counting sort of a batch by class: label int64 [B] -> label_sorted, the rows of u (float64 [B,n]) in that
+    order -> u_sorted, perm int32 [B] (sorted position -> original row).  One launch."""
+    _need_gpu(label, u, label_sorted, u_sorted, perm)
+    B = label.numel()
+    if label.dtype != torch.int64 or label_sorted.dtype != torch.int64 or perm.dtype != torch.int32 or label_sorted.numel() != B \
+            or perm.numel() != B:
+        raise RuntimeError("prior_class_order: int64 labels, int32 permutation, one entry per row")
+    n_cols = 0
+    if u is not None:
+        if u.dtype != torch.float64 or u_sorted is None or u_sorted.dtype != torch.float64 or u.shape != u_sorted.shape or u.shape[0] != B:
+            raise RuntimeError("prior_class_order: u and u_sorted must be float64 [B,n]")
+        n_cols = int(u.shape[1])
+    with torch.cuda.device(label.device):
+        rc = _lib.load().dvq_prior_class_order(_p(label), _p(u), B, n_cols, int(n_classes), _p(label_sorted), _p(u_sorted), _p(perm),
+                                               _stream(label))
+    _lib.check(rc, "dvq_prior_class_order")
+
+
+def unpermute_rows(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    """out[perm[r]] = x[r] for int64 rows [B,n]."""
+    _need_gpu(x, perm)
+    if x.dtype != torch.int64 or x.dim() != 2 or perm.dtype != torch.int32 or perm.numel() != x.shape[0]:
+        raise RuntimeError("unpermute_rows: int64 [B,n] rows and an int32 [B] permutation expected")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().dvq_unpermute_rows(_p(x), _p(perm), x.shape[0], x.shape[1], _p(out), _stream(x))
+    _lib.check(rc, "dvq_unpermute_rows")
+    return out
+
+
 # ------------------------------------------------------------------------- MANO
 def mano_lbs(global_orient, hand_pose, transl, consts: DvqManoConsts, n_verts: int,
              want_joints: bool = True, want_full_pose: bool = False, want_v_posed: bool = False,
              verts: Optional[torch.Tensor] = None, v_posed: Optional[torch.Tensor] = None):
     """MANO forward.  Returns (verts, joints, full_pose) and, with want_v_posed, the blend-shaped rest
-    vertices the backward pass needs as a fourth element.  `verts` / `v_posed` may be preallocated."""
-    _need_gpu(global_orient, hand_pose, transl)
+    vertices the backward pass needs as a fourth element.  `verts` / `v_posed` may be preallocated.  The three inputs
+    may be column ranges of wider row-major buffers (their rows must be contiguous); global_orient=None stands for
+    zeros, transl=None for no translation."""
     B = hand_pose.shape[0]
     dev = hand_pose.device
+
+    def rows(t, width, what):
+        """Row stride of a [B, width] input whose rows are contiguous (a column range of a wider buffer is fine)."""
+        if t is None:
+            return 0
+        if not t.is_cuda:
+            raise RuntimeError("dvq_hip kernels need tensors on a HIP device (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.float32 or t.dim() != 2 or t.shape != (B, width) or (width > 1 and t.stride(1) != 1):
+            raise RuntimeError(f"mano_lbs: {what} must be float32 [B,{width}] with contiguous rows")
+        return max(int(t.stride(0)), width) if B > 1 else width
+    ld_go = rows(global_orient, 3, "global_orient")
+    ld_hp = rows(hand_pose, consts.n_comps, "hand_pose")
+    ld_tr = rows(transl, 3, "transl")
     if verts is None:
         verts = torch.empty(B, n_verts, 3, dtype=torch.float32, device=dev)
     joints = torch.empty(B, 16, 3, dtype=torch.float32, device=dev) if want_joints else None
@@ -334,10 +410,10 @@ def mano_lbs(global_orient, hand_pose, transl, consts: DvqManoConsts, n_verts: i
     if want_v_posed and v_posed is None:
         v_posed = torch.empty(B, n_verts, 3, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _timed("mano_lbs", (B,), hand_pose):
-        rc = _lib.load().dvq_mano_lbs(_p(global_orient), _p(hand_pose), _p(transl), B, ctypes.byref(consts),
-                                      _p(verts), _p(joints), _p(full), _p(v_posed) if want_v_posed else None,
-                                      _stream(hand_pose))
-    _lib.check(rc, "dvq_mano_lbs")
+        rc = _lib.load().dvq_mano_lbs_rows(_p(global_orient), ld_go, _p(hand_pose), ld_hp, _p(transl), ld_tr, B,
+                                           ctypes.byref(consts), _p(verts), _p(joints), _p(full),
+                                           _p(v_posed) if want_v_posed else None, _stream(hand_pose))
+    _lib.check(rc, "dvq_mano_lbs_rows")
     if want_v_posed:
         return verts, joints, full, v_posed
     return verts, joints, full

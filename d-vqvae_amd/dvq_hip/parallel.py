@@ -71,8 +71,11 @@ def gather_rows(t: torch.Tensor, n_total: Optional[int] = None, async_op: bool =
     is padded to ceil(n_total/world) rows for the collective and the padding is trimmed from the result; a block
     of any other size is refused (every rank must bring the same number of rows or the collective mismatches).
     Without it all ranks must pass equally sized blocks.
-    With async_op=True returns (rows, work): the collective runs beside whatever is launched next, and `rows` is
-    complete once work.wait() has been called (work is None when there is nothing to exchange)."""
+    With async_op=True returns (rows, work), and `rows` is complete once work.wait() has been called (work is None
+    when there is nothing to exchange); the caller MUST call it.  Over RCCL the collective is issued here and runs
+    beside whatever is launched next.  Over gloo with device tensors (the one-GPU rehearsal) only the device-to-host
+    copy is issued here: the host collective itself runs inside work.wait(), so nothing overlaps, and a rank that
+    drops its handle without waiting never enters the collective and hangs its peers."""
     rank, ws = world()
     if ws == 1:
         out = t if n_total is None else t[:n_total]

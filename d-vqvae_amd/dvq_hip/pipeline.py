@@ -15,7 +15,9 @@ from .mano_io import Struct
 
 def assemble_param(recon: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
     """[betas10 | global_orient3 | pose45 | transl3]  (gen_diverse_grasp_obman.py:243-247)"""
-    return torch.cat([recon[:, 0:10], pos[:, 0:3], recon[:, 10:55], pos[:, 3:6]], 1)     # one launch
+    if recon.is_cuda:
+        return ops.assemble_param(recon, pos)                                            # one launch
+    return torch.cat([recon[:, 0:10], pos[:, 0:3], recon[:, 10:55], pos[:, 3:6]], 1)
 
 
 class GraspGenerator:
@@ -63,8 +65,10 @@ class GraspGenerator:
         if self._in_flight and x_tilde is None and prior is not None and not prior.graph_ready(B):
             self.finish()            # the prior is about to record a HIP graph: no collective may be pending then
         if B == 0:
+            # an empty shard still takes part in the gather: its blocks must have the other ranks' row shape
+            n_verts = int(self.rh_mano.v_template.shape[0])
             param = torch.zeros((0, 61), dtype=torch.float32, device=obj.device)
-            verts = torch.zeros((0, 778, 3), dtype=torch.float32, device=obj.device)
+            verts = torch.zeros((0, n_verts, 3), dtype=torch.float32, device=obj.device)
         elif x_tilde is None:
             if obj.is_cuda:
                 u = ops.prior_uniforms(first_id, B, 9, self.seed, obj.device)      # = rng.uniforms of these ids
@@ -75,8 +79,9 @@ class GraspGenerator:
             recon, pos = self.model.gen(obj, x_tilde=x_tilde)
         if B > 0:
             param = assemble_param(recon, pos)
-            out = self.rh_mano(betas=param[:, :10], global_orient=param[:, 10:13].contiguous(),
-                               hand_pose=param[:, 13:58].contiguous(), transl=param[:, 58:].contiguous())
+            # the three slices of the parameter vector are read in place (row stride 61)
+            out = self.rh_mano(betas=param[:, :10], global_orient=param[:, 10:13], hand_pose=param[:, 13:58],
+                               transl=param[:, 58:])
             verts = out.vertices
         if gather and async_gather:
             verts, wv = parallel.gather_rows(verts, n_total, async_op=True)

@@ -223,7 +223,15 @@ class MANO(nn.Module):
                               keep['posedirs_lanes'].data_ptr() if has_table else None)
             self._consts = (c, keep)
             self._consts_key = key
+            self._pose_mean_is_zero = bool((self.pose_mean == 0).all())     # flat_hand_mean: x - 0 == x, no launch needed
         return self._consts[0]
+
+    @torch.no_grad()
+    def hip_vertices(self, hand_pose, global_orient=None, transl=None):
+        """Vertices [B,V,3] only, for callers inside this package: global_orient=None / transl=None stand for zeros (what
+        gen() passes, gen_net.py:114-118) without a zero tensor being made, and the inputs may be column ranges of wider
+        buffers.  forward() keeps the reference's meaning of None (the module's own parameters)."""
+        return ops.mano_lbs(global_orient, hand_pose, transl, self._device_consts(), self.v_template.shape[0], False, False)[0]
 
     def forward(self, betas=None, global_orient=None, hand_pose=None, transl=None, return_verts=True,
                 return_tips=False, return_full_pose=False, pose2rot=True, **kwargs):
@@ -239,8 +247,14 @@ class MANO(nn.Module):
         vertices = joints = full_pose = None
         want_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (global_orient, hand_pose, transl))
         keep = (lambda t: t) if want_grad else (lambda t: t.detach())
-        hp = keep(hand_pose).to(torch.float32).contiguous()
-        go = keep(global_orient).to(torch.float32).contiguous()
+
+        def as_rows(t):
+            """float32 with contiguous rows: a column range of a wider buffer (the call sites' slices of the 61-d
+            parameter vector) is passed to the kernel as it is, anything else is copied."""
+            t = keep(t).to(torch.float32)
+            return t if (t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1) and not want_grad) else t.contiguous()
+        hp = as_rows(hand_pose)
+        go = as_rows(global_orient)
         B = hp.shape[0]
 
         def rows(t, what):   # the module's own batch-1 defaults broadcast, as in the reference
@@ -252,7 +266,7 @@ class MANO(nn.Module):
         go = rows(go, "global_orient")
         tr = None
         if transl is not None:
-            tr = rows(keep(transl).to(torch.float32).contiguous(), "transl")
+            tr = rows(as_rows(transl), "transl")
         if return_verts:
             if want_grad:
                 vertices, joints, full_pose = _LbsFunction.apply(go, hp, tr, self)
@@ -266,6 +280,11 @@ class MANO(nn.Module):
             pose = hp @ self.hand_components if self.use_pca else hp
             full_pose = torch.cat([go, pose], dim=1) + self.pose_mean
         # the reference returns the PCA-expanded pose in `hand_pose` (model.py:328,356)
-        pose45 = full_pose[:, 3:] - self.pose_mean[3:] if full_pose is not None else hand_pose
+        if full_pose is None:
+            pose45 = hand_pose
+        elif getattr(self, '_pose_mean_is_zero', False):
+            pose45 = full_pose[:, 3:]
+        else:
+            pose45 = full_pose[:, 3:] - self.pose_mean[3:]
         return ModelOutput(vertices=vertices, joints=joints, betas=betas, global_orient=global_orient,
                            hand_pose=pose45, full_pose=full_pose if return_full_pose else None)

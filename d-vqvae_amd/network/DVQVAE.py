@@ -80,17 +80,29 @@ class Decoder(nn.Module):
         if (bf16 and first.is_cuda and len(layers) == 3
                 and ops.head_shapes_ok(first.shape[0], widths, layers[0].out_features, layers[1].out_features)):
             W0, W1 = layers[0].weight.detach(), layers[1].weight.detach()
-            key = (W0.data_ptr(), W0._version, W1.data_ptr(), W1._version, tuple(widths))
-            if getattr(self, "_head_key", None) != key:
-                self._head = ops.head_pack(W0, widths, W1)
-                self._head_key = key
-            x = ops.head_mlp_bf16([pc if isinstance(pc, tuple) else pc.detach().contiguous() for pc in pieces], self._head,
+            # packed weights per split of the input into pieces (forward(z) brings one piece, gen() seven): callers that
+            # alternate between splits do not re-pack; a new weight version drops them all
+            wkey = (W0.data_ptr(), W0._version, W1.data_ptr(), W1._version)
+            if getattr(self, "_head_wkey", None) != wkey:
+                self._heads, self._head_wkey = {}, wkey
+            head = self._heads.get(tuple(widths))
+            if head is None:
+                head = self._heads[tuple(widths)] = ops.head_pack(W0, widths, W1)
+            x = ops.head_mlp_bf16([pc if isinstance(pc, tuple) else pc.detach().contiguous() for pc in pieces], head,
                                   layers[0].bias.detach(), layers[1].bias.detach())
             return _linear(layers[2], x)
-        xs = []
-        for pc in pieces:
-            xs.append(ops.vq_gather(pc[0].contiguous(), pc[1]) if isinstance(pc, tuple) else pc.detach())
-        x = xs[0] if len(xs) == 1 else torch.cat(xs, 1)
+        if len(pieces) == 1 and not isinstance(pieces[0], tuple):
+            x = pieces[0].detach()
+        else:
+            # the concatenation (gen_net.py:101-109), codebook rows gathered straight into their column range
+            x = torch.empty(first.shape[0], sum(widths), dtype=torch.float32, device=first.device)
+            col = 0
+            for pc, w in zip(pieces, widths):
+                if isinstance(pc, tuple):
+                    ops.vq_gather(pc[0].contiguous(), pc[1], out=x[:, col:col + w])
+                else:
+                    x[:, col:col + w] = pc.detach()
+                col += w
         for i, m in enumerate(layers):
             x = _linear(m, x, relu=(i + 1 < len(layers)), bf16=bf16)
         return x

@@ -51,10 +51,16 @@ class GenNet(nn.Module):
         # six codebook rows and the un-quantised object feature (gen_net.py:109), handed to the decoder piece by piece
         pieces = [(part_idx[k], getattr(self, f"vqvae{k}").vector_quantization.embedding.weight.detach()) for k in range(6)]
         recon = self.decoder.forward_pieces(pieces + [obj_feat_type]).view(B, 55)
-        zero3 = torch.zeros(B, 3, dtype=torch.float32, device=recon.device)
-        verts = self.rh_mano(betas=recon[:, :10], global_orient=zero3, hand_pose=recon[:, 10:55].contiguous(),
-                             transl=zero3).vertices
-        hand_feat, _, _ = self.recon_encoder(verts.detach().permute(0, 2, 1).contiguous())
+        if hasattr(self.rh_mano, "hip_vertices") and recon.is_cuda:
+            # zero orientation and translation (gen_net.py:114-118) without the zero tensors, the pose coefficients read
+            # in place from the decoder's output
+            verts = self.rh_mano.hip_vertices(recon[:, 10:55])
+        else:
+            zero3 = torch.zeros(B, 3, dtype=torch.float32, device=recon.device)
+            verts = self.rh_mano(betas=recon[:, :10], global_orient=zero3, hand_pose=recon[:, 10:55].contiguous(),
+                                 transl=zero3).vertices
+        # [B,778,3] seen as [B,3,778] (gen_net.py:120): the encoder reads the point-major buffer in place
+        hand_feat, _, _ = self.recon_encoder(verts.detach().permute(0, 2, 1))
         pos = self.pos_decoder.forward_pieces([hand_feat, obj_feat_pos]).view(B, 6)
         return recon, pos
 
@@ -69,7 +75,8 @@ class GenNet(nn.Module):
             (obj_feat_type, _, _), (obj_feat_pos, _, _) = encode_together([self.obj_encoder_type, self.obj_encoder_pos], obj)
         else:
             obj_feat_type, _, _ = self.obj_encoder_type(obj)
-        idx6, _obj_emb = self.vqvae6.inference(obj_feat_type)
+        # (the reference also fetches the quantised object feature here and never uses it, gen_net.py:83: only the index)
+        idx6 = self.vqvae6.vector_quantization.search(obj_feat_type)
         # The position encoder does not depend on the prior, but running it beside the prior on a stream of its own
         # gains nothing: an encoder workgroup pair fills a SIMD's registers, the prior's launches then wait for
         # slots and both slow down (17.1 ms against 17.0 ms per 4096 objects one after the other).

@@ -198,7 +198,8 @@ class GatedPixelCNN(nn.Module):
             logits=torch.empty(B, self.output_conv[2].out_channels, dtype=torch.float32, device=dev),
             emb=self.embedding.weight.detach().float().contiguous(),
             label=torch.zeros(B, dtype=torch.int64, device=dev),
-            u=torch.zeros(B, H * W, dtype=torch.float64, device=dev), graph=None, x=None)
+            u=torch.zeros(B, H * W, dtype=torch.float64, device=dev),
+            perm=torch.zeros(B, dtype=torch.int32, device=dev), graph=None, x=None)
 
     @torch.no_grad()
     def generate(self, x_start, label, shape=(3, 3), batch_size=64, generator=None, return_probs=False,
@@ -218,21 +219,30 @@ class GatedPixelCNN(nn.Module):
         dev = self.embedding.weight.device
         if not self.embedding.weight.is_cuda:
             raise RuntimeError("GatedPixelCNN.generate needs the module on a HIP device (there is no CPU path)")
-        if self.sort_by_class and B >= self.sort_min_rows and uniforms is not None and not return_probs and not _sorted:
-            # rows are independent and a row's arithmetic does not depend on its position: same grids, row for row
-            lab, perm = torch.sort(label.reshape(-1).to(torch.int64))
-            xs = self.generate(x_start, lab, shape, B, generator, False, uniforms[perm], _sorted=True)
-            x = torch.empty_like(xs)
-            x[perm] = xs
-            return x
         self._prepared_hip()
         bufs = self._act_buffers(B, H, W, dev)
-        bufs["label"].copy_(label.reshape(-1).to(torch.int64))
+        n_classes = self.layers[0].class_cond_embedding.num_embeddings
+        ordered = (self.sort_by_class and B >= self.sort_min_rows and uniforms is not None and not return_probs
+                   and not _sorted and n_classes <= ops.PRIOR_ORDER_MAX_CLASSES)
+        if ordered:
+            # Rows are independent and a row's arithmetic does not depend on its position, so the batch is evaluated in
+            # class order (a tile's epilogue then reads a few rows of the per-class tables instead of one per sample)
+            # and the grids are handed back in the caller's order: same grids, row for row.  One launch writes the
+            # sorted labels, the uniforms in that order and the permutation (a stable counting sort).
+            ops.prior_class_order(label.reshape(-1).to(torch.int64), uniforms, n_classes, bufs["label"], bufs["u"], bufs["perm"])
+            uniforms = bufs["u"]
+        else:
+            bufs["label"].copy_(label.reshape(-1).to(torch.int64))
         if self._by_class(B):
             self._class_rows(shape, B >= self.vrow_min_rows)        # before any graph is recorded
+        def caller_order(x):
+            return ops.unpermute_rows(x.view(B, H * W), bufs["perm"]).view(B, H, W) if ordered else x
+
         if uniforms is None or return_probs or not self.use_graph:
-            return self._run_hip(bufs, shape, B, generator, return_probs, uniforms)
-        bufs["u"].copy_(uniforms)
+            out = self._run_hip(bufs, shape, B, generator, return_probs, uniforms)
+            return caller_order(out) if not return_probs else out
+        if not ordered:
+            bufs["u"].copy_(uniforms)
         if bufs.get("graph") is None or bufs.get("split") != self._plan(B):
             n_parts = self._n_parts(B)
             parts = None
@@ -276,7 +286,7 @@ class GatedPixelCNN(nn.Module):
                     g.replay()
             for _, _, _, st in bufs["parts"]:
                 main.wait_stream(st)
-        return bufs["x"].clone()
+        return caller_order(bufs["x"]) if ordered else bufs["x"].clone()
 
     def _plan(self, B):
         """What a recorded graph of batch size B depends on besides the weights."""
@@ -436,7 +446,7 @@ class GatedPixelCNN(nn.Module):
         XV, logits = bufs["XV"], bufs["logits"]
         emb = bufs["emb"]
         label = bufs["label"]
-        x = torch.zeros((B, H, W), dtype=torch.int64, device=dev) if x_out is None else x_out
+        x = torch.empty((B, H, W), dtype=torch.int64, device=dev) if x_out is None else x_out    # every cell is written below
         probs_all = []
         use_vrow = B >= self.vrow_min_rows
         by_class = self._by_class(B)

@@ -57,7 +57,10 @@ def _check_input(module, x, channel):
                            "(BatchNorm batch statistics are not implemented)")
     if x.dim() != 3 or x.shape[1] != channel:
         raise RuntimeError(f"expected x [B,{channel},N], got {tuple(x.shape)}")
-    return x.detach().to(torch.float32).contiguous()
+    x = x.detach().to(torch.float32)
+    if ops.is_point_major(x):
+        return x         # a [B,N,C] buffer seen as [B,C,N] (e.g. vertices.permute(0, 2, 1)): the kernels read it in place
+    return x.contiguous()
 
 
 class STN3d(nn.Module):
@@ -185,7 +188,7 @@ def encode_together(encoders, x):
            for e in encoders):
         raise RuntimeError("encode_together: encoders must share channel count, compute dtype and the global-feature path")
     for e in encoders:
-        x = _check_input(e, x, e.channel)
+        x = _check_input(e, x, e.channel).contiguous()       # (the grouped launches take channel-major clouds)
         e.stn.compute_dtype = e.compute_dtype
     code = _dtype_code(e0.compute_dtype)
     stn = [e.stn._packed() for e in encoders]                      # (trunk, (w4, b4, w4h), (w5, b5, w5h))

@@ -38,6 +38,12 @@ class VectorQuantizer(nn.Module):
         idx, z_q = ops.vq_argmin(z_flat.detach().contiguous(), w, want_zq=True, prepared=self._prepared())
         return idx.unsqueeze(1), z_q
 
+    def search(self, z):
+        """Indices only, int64 [n,1] (forward(z, False)[0] without gathering the rows)."""
+        z_flat = z.reshape(-1, self.e_dim)
+        idx, _ = ops.vq_argmin(z_flat.detach().contiguous(), self.embedding.weight.detach(), want_zq=False, prepared=self._prepared())
+        return idx.unsqueeze(1)
+
     def forward(self, z, istrain):
         z_flat = z.reshape(-1, self.e_dim)
         idx, z_q = self._search(z_flat)

@@ -98,7 +98,8 @@ int dvq_vq_gather(const int64_t* idx, const float* E, int64_t n, int K, int D,
  * (dvq_fold_bn).  When `trans` is given the xyz channels of every point are first
  * multiplied by the cloud's 3x3 matrix (row vector times matrix, :146).
  *
- * x: float [B,C,N] (channel-major, as the reference's datasets produce), C = 3 or 4.
+ * x: float [B,C,N] (channel-major, as the reference's datasets produce), C = 3 or 4; with point_major != 0 the
+ * same clouds laid out [B,N,C] (what a vertex array is: the permute + copy of gen_net.py:120 is then not needed).
  * trans: float [B,3,3] or NULL.  feat_out: float [B,1024].
  * w3p: A3 packed by dvq_pointnet_pack_w3 for `dtype`.
  */
@@ -113,7 +114,7 @@ typedef struct {
 
 size_t dvq_pointnet_w3_bytes(int dtype);
 int dvq_pointnet_pack_w3(const float* a3 /* [1024,128] */, int dtype, void* w3p, void* stream);
-int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, int C, int N,
+int dvq_pointnet_mlp_max(const float* x, const float* trans, int B, int C, int N, int point_major,
                          const DvqPointMlp* w, int relu3, int dtype, float* feat_out, void* stream);
 
 /* Up to 8 independent dvq_pointnet_mlp_max calls (own clouds, point count, transform and weights each; one C and
@@ -203,6 +204,13 @@ typedef struct {
 int dvq_mano_lbs(const float* global_orient, const float* hand_pose, const float* transl, int B,
                  const DvqManoConsts* m, float* verts_out, float* joints_out, float* full_pose_out,
                  float* v_posed_out, void* stream);
+/* The same with a row stride (in floats) per input, so that the three inputs can be column ranges of wider rows -- the
+ * call sites slice them out of one [B,61] parameter vector (reference: DVQ-VAE/gen_diverse_grasp_obman.py:243-253) and
+ * gen() out of the decoder's [B,55] output (DVQ-VAE/network/gen_net.py:114-118) -- and a NULL global_orient for an
+ * all-zero one (gen() passes zeros there). */
+int dvq_mano_lbs_rows(const float* global_orient, int64_t ld_go, const float* hand_pose, int64_t ld_hp,
+                      const float* transl, int64_t ld_tr, int B, const DvqManoConsts* m, float* verts_out,
+                      float* joints_out, float* full_pose_out, float* v_posed_out, void* stream);
 
 /* Vector-Jacobian product of dvq_mano_lbs's vertices: what autograd computes for the reference's
  * MANO layer when a loss on the vertices is back-propagated to the pose parameters, as the
@@ -323,6 +331,21 @@ typedef struct {
     const float* pre_add[3]; /* optional, per cell: [n_classes, N] added to y_j by label before the gate (part of out_pre) */
 } DvqPriorVRow;
 int dvq_prior_vrow(const DvqPriorVRow* v, int M, int N, void* stream);
+
+/* Class ordering of a batch for the sampling loop (no counterpart in the reference, which samples one grid per call): a
+ * stable counting sort of the rows by label in one launch.  label: int64 [B] (values clamped to 0..n_classes-1,
+ * n_classes <= 1024); u (nullable): float64 [B, n_cols], the rows' uniforms.  Writes label_sorted int64 [B], u_sorted
+ * [B, n_cols] and perm int32 [B] (sorted position -> original row).  dvq_unpermute_rows puts int64 rows computed in
+ * sorted order back: out[perm[r], :] = in[r, :]. */
+int dvq_prior_class_order(const int64_t* label, const double* u, int64_t B, int n_cols, int n_classes,
+                          int64_t* label_sorted, double* u_sorted, int* perm, void* stream);
+int dvq_unpermute_rows(const int64_t* in, const int* perm, int64_t B, int n_cols, int64_t* out, void* stream);
+
+/* The call sites' parameter vector (reference: DVQ-VAE/gen_diverse_grasp_obman.py:243-247, same in the ho3d / FHAB /
+ * grab / HDMO scripts): param[:,0:10] = recon[:,0:10]; [10:13] = pos[:,0:3]; [13:58] = recon[:,10:55]; [58:61] =
+ * pos[:,3:6].  recon: [B,55] with row stride ld_recon, pos: [B,6] with row stride ld_pos, param: [B,61] contiguous. */
+int dvq_assemble_param(const float* recon, int64_t ld_recon, const float* pos, int64_t ld_pos, int64_t B, float* param,
+                       void* stream);
 
 /* One cell of the sampling loop (models.py:189-196): p = softmax(logits[m, :]) / sum, x = inverse CDF of p at the
  * uniform u[m*u_stride] in [0,1) (fp64 running sum; the number of cdf entries <= u, clamped to n_classes-1), written to

@@ -276,3 +276,64 @@ def test_head_mlp_bf16_pieces_equal_the_concatenated_input():
         assert (got.double() - want).abs().max().item() <= 4e-3 * scale
         old = ops.linear(ops.linear(x, W0, b0, relu=True, W_bf16=ops.to_bf16(W0)), W1, b1, relu=True, W_bf16=ops.to_bf16(W1))
         assert (got - old).abs().max().item() <= 4e-3 * scale
+
+
+# ------------------------------------------------------------------ kernels around the step (no framework launches)
+@pytest.mark.parametrize("B", [1, 5, 4096])
+def test_mano_reads_column_ranges_of_the_parameter_vector_in_place(B):
+    """The call sites slice global_orient / hand_pose / transl out of one [B,61] vector
+    (gen_diverse_grasp_obman.py:243-253): the layer reads those slices in place and gives the same bits as on copies;
+    hip_vertices (zero orientation and translation without zero tensors) equals forward with explicit zeros."""
+    rh = make_mano()
+    go, hp, tr = synth.mano_inputs(B, seed=31)
+    param = torch.zeros(B, 61)
+    param[:, 10:13], param[:, 13:58], param[:, 58:] = go, hp, tr
+    param = param.to(DEV)
+    a = rh(betas=param[:, :10], global_orient=param[:, 10:13], hand_pose=param[:, 13:58], transl=param[:, 58:])
+    b = rh(global_orient=go.to(DEV), hand_pose=hp.to(DEV), transl=tr.to(DEV))
+    assert torch.equal(a.vertices, b.vertices) and torch.equal(a.joints, b.joints)
+    z = torch.zeros(B, 3, device=DEV)
+    assert torch.equal(rh.hip_vertices(param[:, 13:58]), rh(global_orient=z, hand_pose=hp.to(DEV), transl=z).vertices)
+    assert torch.equal(rh.hip_vertices(param[:, 13:58], param[:, 10:13], param[:, 58:]), b.vertices)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,N", [(3, 778), (3, 83), (4, 3000)])
+def test_pointnet_reads_point_major_clouds_in_place(dtype, C, N):
+    """A [B,N,C] buffer seen as [B,C,N] (vertices.permute(0, 2, 1), gen_net.py:120) gives the bits of its
+    channel-major copy, transform net included."""
+    from network.pointnet_encoder import PointNetEncoder
+    sd = synth.gennet_state_dict(0, with_prior=False)
+    pre = "recon_encoder." if C == 3 else "obj_encoder_pos."
+    enc = PointNetEncoder(channel=C)
+    enc.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+    enc = enc.to(DEV).eval()
+    enc.compute_dtype = dtype
+    pts = (0.05 * torch.randn(37, N, C, generator=torch.Generator().manual_seed(N))).to(DEV)      # [B,N,C]
+    view = pts.permute(0, 2, 1)
+    assert ops.is_point_major(view) and not ops.is_point_major(view.contiguous())
+    f0, t0, _ = enc(view.contiguous())
+    f1, t1, _ = enc(view)
+    assert torch.equal(f0, f1) and torch.equal(t0, t1)
+
+
+def test_assemble_param_and_class_order_kernels():
+    g = torch.Generator().manual_seed(5)
+    recon, pos = torch.randn(1000, 55, generator=g).to(DEV), torch.randn(1000, 6, generator=g).to(DEV)
+    want = torch.cat([recon[:, 0:10], pos[:, 0:3], recon[:, 10:55], pos[:, 3:6]], 1)
+    assert torch.equal(ops.assemble_param(recon, pos), want)
+    wide = torch.randn(1000, 80, generator=g).to(DEV)
+    assert torch.equal(ops.assemble_param(wide[:, 7:62], pos), torch.cat([wide[:, 7:17], pos[:, 0:3], wide[:, 17:62], pos[:, 3:6]], 1))
+    for B, n_classes in ((1, 128), (63, 128), (64, 5), (4096, 128), (5000, 1), (70001, 1000)):
+        label = torch.randint(0, n_classes, (B,), generator=g).to(DEV)
+        u = torch.rand(B, 9, dtype=torch.float64, generator=g).to(DEV)
+        ls, us, perm = torch.empty_like(label), torch.empty_like(u), torch.empty(B, dtype=torch.int32, device=DEV)
+        ops.prior_class_order(label, u, n_classes, ls, us, perm)
+        want_l, want_p = torch.sort(label, stable=True)
+        assert torch.equal(perm.long(), want_p), (B, n_classes)          # the stable order: independent of timing
+        assert torch.equal(ls, want_l) and torch.equal(us, u[want_p])
+        x = torch.randint(0, 128, (B, 9), generator=g).to(DEV)
+        back = ops.unpermute_rows(x, perm)
+        want_x = torch.empty_like(x)
+        want_x[want_p] = x
+        assert torch.equal(back, want_x)

@@ -94,8 +94,12 @@ class _StubModel:
 
 
 class _StubHand:
+    """A hand layer with another vertex count than MANO's 778: an empty shard must still gather blocks of this shape."""
+    V = 50
+    v_template = torch.zeros(V, 3)
+
     def __call__(self, betas, global_orient, hand_pose, transl):
-        v = hand_pose.sum(1).reshape(-1, 1, 1) + torch.arange(778.0 * 3).reshape(1, 778, 3) + transl.unsqueeze(1)
+        v = hand_pose.sum(1).reshape(-1, 1, 1) + torch.arange(self.V * 3.0).reshape(1, self.V, 3) + transl.unsqueeze(1)
         return types.SimpleNamespace(vertices=v)
 
 
@@ -137,7 +141,7 @@ def test_ragged_and_empty_shards_through_the_generator():
             p.join(timeout=120)
             assert p.exitcode == 0
         want = GraspGenerator(_StubModel(), _StubHand(), seed=1).generate(synth.object_clouds(n, 64, seed=5))
-        assert verts.shape == (n, 778, 3) and param.shape == (n, 61)
+        assert verts.shape == (n, _StubHand.V, 3) and param.shape == (n, 61)
         np.testing.assert_array_equal(verts, want["vertices"].numpy())
         np.testing.assert_array_equal(param, want["recon_param"].numpy())
 
