@@ -457,7 +457,7 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_kernel(VqBatch vb, 
 // A slot that starts at quarter j > 0 meets the codes of quarters 0..j-1 after those of j..3: at the wrap its
 // running winner is set aside, and when the two parts are merged the winner among the LOWER codes takes equal
 // scores, so ties still resolve to the lowest index.
-template <int D, int WAVES>
+template <int D, int WAVES, bool STAGGER>
 __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_rot_kernel(
     const unsigned short* __restrict__ z, const char* __restrict__ packed, int64_t n, int n_tiles, int TS,
     int64_t* __restrict__ idx_out) {
@@ -574,6 +574,16 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_rot_kernel(
     };
 
     int g = 0;               // stages consumed so far; stage g sits in buffer g&1
+    // STAGGER: the two waves of a SIMD (wave w and w + 4) run half a stage apart.  Every wave meets a barrier twice per
+    // stage, at its middle and at its end; for waves 0-3 ("early", GRP 0) a stage ends where it is half done for waves
+    // 4-7 ("late", GRP 1), so whenever one wave of a SIMD is busy with what surrounds a stage boundary -- refilling a
+    // slot, storing a tile, issuing the copies and the row prefetch -- the other is in the middle of its matrix
+    // instructions and keeps the pipe fed (without this both waves of every SIMD do that work at the same time, right
+    // behind the barrier).  Time in half stages h: the early waves compute stage s in h = 2s, 2s+1, the late ones in
+    // h = 2s+1, 2s+2; all waves issue their share of the copies of stage s+1 at the start of an odd h = 2s+1 (the
+    // buffer's previous stage s-1 was last read in h = 2s) and wait for them at its end (first read in h = 2s+2).
+    // The late waves pass one barrier before their first stage, the early ones one after their last: same count.
+    const int GRP = (STAGGER && wave >= WAVES / 2) ? 1 : 0;   // wave-uniform: 0 early wave, 1 late wave
     auto phase = [&](auto q_const, int p) {
         constexpr int Q = decltype(q_const)::value;
         // slot Q starts tile p ...
@@ -608,22 +618,42 @@ __global__ __launch_bounds__(WAVES * 64) void vq_argmax_bf16_rot_kernel(
             const char* eb = smem + (g & 1) * stage_bytes;
             const int t_first = cs * TS;
             const int t_count = (n_tiles - t_first) < TS ? (n_tiles - t_first) : TS;
-            if (more) issue_stage(cs + 1 == n_stages ? 0 : cs + 1, (g + 1) & 1);
-            if (zload) load_tile(p + 1);     // issued after the stage's copies: a counted wait can leave it in flight
-            code_tile(std::false_type{}, eb, t_first * 32);
-            for (int t = 1; t < t_count; ++t) code_tile(std::true_type{}, eb + t * TILE_BYTES, (t_first + t) * 32);
-            flush_pending();
-            if (zload) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!STAGGER) {
+                if (more) issue_stage(cs + 1 == n_stages ? 0 : cs + 1, (g + 1) & 1);
+                if (zload) load_tile(p + 1);     // issued after the stage's copies: a counted wait can leave it in flight
+                code_tile(std::false_type{}, eb, t_first * 32);
+                for (int t = 1; t < t_count; ++t) code_tile(std::true_type{}, eb + t * TILE_BYTES, (t_first + t) * 32);
+                flush_pending();
+                if (zload) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                const int t_half = (t_count + 1) / 2;
+                if (GRP == 1 && more) issue_stage(cs + 1 == n_stages ? 0 : cs + 1, (g + 1) & 1);   // start of an odd half stage
+                if (zload) load_tile(p + 1);
+                code_tile(std::false_type{}, eb, t_first * 32);
+                for (int t = 1; t < t_half; ++t) code_tile(std::true_type{}, eb + t * TILE_BYTES, (t_first + t) * 32);
+                if (GRP == 1) {                  // end of the odd half stage: this wave's copies have landed
+                    if (zload) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                if (GRP == 0 && more) issue_stage(cs + 1 == n_stages ? 0 : cs + 1, (g + 1) & 1);   // start of an odd half stage
+                for (int t = t_half; t < t_count; ++t) code_tile(std::true_type{}, eb + t * TILE_BYTES, (t_first + t) * 32);
+                flush_pending();
+                if (GRP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the copies, and the rows requested before them
+                __builtin_amdgcn_s_barrier();
+            }
         }
     };
+    if (STAGGER && GRP == 1) __builtin_amdgcn_s_barrier();       // the early waves' first half stage
     for (int p0 = 0; p0 < cnt; p0 += 4) {
         phase(std::integral_constant<int, 0>{}, p0);
         phase(std::integral_constant<int, 1>{}, p0 + 1);
         phase(std::integral_constant<int, 2>{}, p0 + 2);
         phase(std::integral_constant<int, 3>{}, p0 + 3);
     }
+    if (STAGGER && GRP == 0) __builtin_amdgcn_s_barrier();       // the late waves' last half stage
     store_tile(cnt - 4, best[0], bidx[0]);
     // the last tiles of slots 1..3: quarters j..3 just now, quarters 0..j-1 (lower codes) in the first phases
 #pragma unroll
@@ -1049,7 +1079,9 @@ static int launch_bf16_rot(const void* z, const char* ws, const VqPlan& p, int64
     int TS = (68 * 1024) / TILE_BYTES;
     if (TS > p.n_tiles / 4) TS = p.n_tiles / 4;
     const size_t lds = (size_t)2 * TS * TILE_BYTES;
-    auto kern = vq_argmax_bf16_rot_kernel<D, WAVES>;
+    // the two waves of every SIMD half a stage apart: +1 to +1.3 points of the matrix peak at 1024 and 2048 codes, +0.5 to
+    // +1 at 512 (same box, alternating runs), same results
+    auto kern = vq_argmax_bf16_rot_kernel<D, WAVES, true>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "vq_argmin")) return rc;
     const int64_t n_zt = (n + 15) / 16;
     const int64_t blocks = (n_zt + WAVES * 4 - 1) / (WAVES * 4);   // at least one full rotation per wave
