@@ -170,6 +170,14 @@ def vq_microbench(device, n_rows=1 << 20, iters=5):
             if D == 256 and K <= 512:
                 idx, _ = ops.vq_argmin(z, E, want_zq=False, prepared=ws)
                 rec["near_ties_4096_row_sample"] = near_ties(z[:4096], E, idx[:4096])
+                if dist == "B":
+                    # the same codebook on latents placed between two codes (gap of the order of the fp32 spacing of
+                    # the distances): the rows on which the reference's own rounding decides
+                    a = torch.randint(0, K, (4096,), device=device, generator=g)
+                    b = (a + 1 + torch.randint(0, K - 1, (4096,), device=device, generator=g)) % K
+                    zm = (0.5 * (E[a].double() + E[b].double()) + 1e-5 * torch.randn(4096, D, device=device, generator=g, dtype=torch.float64)).to(dtype)
+                    im, _ = ops.vq_argmin(zm, E, want_zq=False, prepared=ws)
+                    rec["near_ties_between_two_codes_sample"] = near_ties(zm, E, im)
             out.append(rec)
             del z, E, ws
     return out

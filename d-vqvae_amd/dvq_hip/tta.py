@@ -63,6 +63,18 @@ def hand_mesh(faces, n_verts: int, contact_verts: Sequence[int], device):
     return mesh, keep
 
 
+def read_closed_faces(path: str) -> np.ndarray:
+    """The closed hand mesh the reference's adaptation script reads (models/mano/closed_mano_faces.pkl,
+    gen_HDMO_TTA.py:61-62): an integer [F,3] array (1552 faces: the model's 1538 plus 14 over the wrist), from a pickle
+    file read as data (dvq_hip.mano_io: nothing the file names is imported or called) or from a .npy file."""
+    from . import mano_io
+    f = np.load(path, allow_pickle=False) if path.endswith(".npy") else mano_io.read_pickled_arrays(path)
+    f = np.asarray(f)
+    if f.ndim != 2 or f.shape[1] != 3 or not np.issubdtype(f.dtype, np.integer):
+        raise ValueError(f"{path}: expected an integer [F,3] face array, got {f.dtype} {f.shape}")
+    return f.astype(np.int64)
+
+
 class GraspRefiner:
     """refine(obj_pc [B,4,N], recon_param [B,61]) -> adapted parameters, as gen_HDMO_TTA.py:119-152."""
 

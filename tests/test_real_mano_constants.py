@@ -101,6 +101,8 @@ def test_product_layer_reads_the_real_file(real):
 def test_closed_hand_faces(real):
     """closed_mano_faces.pkl (gen_HDMO_TTA.py:61-62): (1552, 3) triangles over the 778 vertices that contain the
     model's own 1538 faces' vertex set and close the wrist -- every edge is shared by exactly two faces."""
+    from dvq_hip.tta import read_closed_faces
+    assert np.array_equal(read_closed_faces(CLOSED), mano_io.read_pickled_arrays(CLOSED).astype(np.int64))
     f = mano_io.read_pickled_arrays(CLOSED)
     assert isinstance(f, np.ndarray) and f.shape == (1552, 3) and np.issubdtype(f.dtype, np.integer)
     f = f.astype(np.int64)
