@@ -35,7 +35,7 @@ extern "C" {
 #define DVQ_F32 0
 #define DVQ_BF16 1
 
-#define DVQ_VERSION 112   /* major*10000 + minor*100 + patch */
+#define DVQ_VERSION 113   /* major*10000 + minor*100 + patch */
 
 int dvq_version(void);
 const char* dvq_last_error(void);

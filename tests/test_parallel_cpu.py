@@ -184,7 +184,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.dvq_version.restype = ctypes.c_int
-    assert lib.dvq_version() == 112
+    assert lib.dvq_version() == 113
 
 
 def test_cpu_tensors_are_refused_everywhere():
