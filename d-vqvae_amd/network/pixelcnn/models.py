@@ -134,12 +134,36 @@ class GatedPixelCNN(nn.Module):
         self.sort_min_rows = 2048              # ... for batches of at least this many rows
 
     def forward(self, x, label):
+        """Logits [B, input_dim, H, W] of the grid x (int64 [B,H,W]) under class `label` (models.py:161-174).  On a HIP
+        device in eval mode the masked convolutions are evaluated cell by cell on the dvq_prior kernels with x as the
+        given history -- the same numbers (the convolutions are causal: cell (i,j) sees only earlier cells), no library
+        convolution; in training mode or on CPU tensors the convolution form below runs (it carries autograd)."""
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            return self._forward_hip(x, label)
+        return self.forward_convs(x, label)
+
+    def forward_convs(self, x, label):
+        """The reference's literal forward on framework convolutions: kept as the independent check of the incremental
+        evaluation (generate_full) and for training."""
         shp = x.size() + (-1,)
         x = self.embedding(x.view(-1)).view(shp).permute(0, 3, 1, 2)
         x_v, x_h = x, x
         for layer in self.layers:
             x_v, x_h = layer(x_v, x_h, label)
         return self.output_conv(x_h)
+
+    @torch.no_grad()
+    def _forward_hip(self, x, label):
+        B, H, W = x.shape
+        dev = x.device
+        self._prepared_hip()
+        bufs = self._act_buffers(B, H, W, dev, part=("forward", 0))      # own buffers: a recorded generate() graph stays
+        bufs["label"].copy_(label.reshape(-1).to(torch.int64))
+        if self._by_class(B):
+            self._class_rows((H, W), B >= self.vrow_min_rows)
+        out = torch.empty(B, self.output_conv[2].out_channels, H, W, dtype=torch.float32, device=dev)
+        self._run_hip(bufs, (H, W), B, None, False, None, forced=x.to(torch.int64).contiguous(), collect=out)
+        return out
 
     # ------------------------------------------------------------------ sampling
     def _code(self):
@@ -437,9 +461,10 @@ class GatedPixelCNN(nn.Module):
             ops.prior_gather_rows(pairs, label, B, V, self._packed_key[1])
         ops.vq_gather(label, cls["logits"], out=bufs["logits"])
 
-    def _run_hip(self, bufs, shape, B, generator, return_probs, uniforms, x_out=None):
+    def _run_hip(self, bufs, shape, B, generator, return_probs, uniforms, x_out=None, forced=None, collect=None):
         """Grid row by grid row: the vertical stack of the row, then per cell the horizontal stack, the head and
-        the draw (with the embedding of the drawn code as the next cell's input)."""
+        the draw (with the embedding of the drawn code as the next cell's input).  With `forced` (int64 [B,H,W]) nothing
+        is drawn: the given codes are the history, and the cells' logits are written to collect[:, :, i, j]."""
         H, W = shape
         code = self._packed_key[1]
         dev = self.embedding.weight.device
@@ -463,6 +488,12 @@ class GatedPixelCNN(nn.Module):
                         self._horizontal_cell(bufs, i, j, B, label, cls["cond_v2h"][j], v2h_tap=False, prev_tap=j != 1)
                     else:
                         self._horizontal_cell(bufs, i, j, B, label)
+                if forced is not None:
+                    if collect is not None:
+                        collect[:, :, i, j] = logits
+                    x[:, i, j] = forced[:, i, j]
+                    ops.prior_embed(x[:, i, j], emb, XV[0][i][j], code)
+                    continue
                 if uniforms is not None and not return_probs:
                     # softmax, draw, grid write and embedding of the drawn code in one launch
                     ops.prior_sample(logits, uniforms[:, i * W + j], x[:, i, j], emb, XV[0][i][j], code)
@@ -489,7 +520,7 @@ class GatedPixelCNN(nn.Module):
         out = []
         for i in range(shape[0]):
             for j in range(shape[1]):
-                probs = F.softmax(self.forward(x, label)[:, :, i, j], -1)
+                probs = F.softmax(self.forward_convs(x, label)[:, :, i, j], -1)
                 out.append(probs / probs.sum(dim=1, keepdim=True))
                 x[:, i, j] = forced[:, i, j]
         return torch.stack(out, 1)

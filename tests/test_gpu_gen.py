@@ -60,8 +60,17 @@ def test_prior_logits_and_sampling():
     xt = torch.from_numpy(g["x_tilde"][:2]).to(DEV)
     lab = torch.from_numpy(g["idx6"][:2]).to(DEV)
     with torch.no_grad():
-        lg = model.GatedPixelCNN(xt, lab)
-    np.testing.assert_allclose(lg[:, :128].cpu().numpy(), g["prior_logits"], rtol=2e-3, atol=2e-3)
+        lg = model.GatedPixelCNN(xt, lab)                      # forward() on the HIP kernels (eval, no grad)
+        lg_convs = model.GatedPixelCNN.forward_convs(xt, lab)  # the literal convolution form on framework ops
+    assert lg.shape == (2, 512, 3, 3)
+    np.testing.assert_allclose(lg[:, :128].cpu().numpy(), g["prior_logits"], rtol=2e-4, atol=2e-4)   # vs the reference itself
+    np.testing.assert_allclose(lg_convs[:, :128].cpu().numpy(), g["prior_logits"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(lg.cpu().numpy()[:, :128], lg_convs.cpu().numpy()[:, :128], rtol=2e-3, atol=2e-3)
+    x37 = torch.randint(0, 128, (37, 3, 3), generator=torch.Generator().manual_seed(1)).to(DEV)     # a ragged batch
+    l37 = torch.randint(0, 128, (37,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    with torch.no_grad():
+        a, b = model.GatedPixelCNN(x37, l37), model.GatedPixelCNN.forward_convs(x37, l37)
+    np.testing.assert_allclose(a.cpu().numpy()[:, :128], b.cpu().numpy()[:, :128], rtol=2e-3, atol=2e-3)
     gen = torch.Generator(DEV).manual_seed(3)
     x = model.GatedPixelCNN.generate(None, lab, shape=(3, 3), batch_size=2, generator=gen)
     assert x.shape == (2, 3, 3) and x.dtype == torch.int64 and int(x.max()) < 128
