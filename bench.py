@@ -314,6 +314,9 @@ def main():
                     help="also refine every generated grasp with this many test-time-adaptation steps inside the timed step "
                          "(the reference's adaptation script uses 300); default 0 = generation only")
     ap.add_argument("--no-extras", action="store_true", help="skip the VQ microbench, the variants and the CPU baseline")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: initialise a one-rank process group anyway and issue every collective of the "
+                         "multi-rank path (a rehearsal of the RCCL path on a box with one GPU; sets DVQ_FORCE_COLLECTIVE=1)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; 'gloo' rehearses the multi-rank path with several ranks on ONE GPU "
                          "(RCCL refuses two ranks per device)")
@@ -326,14 +329,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist:
+        os.environ["DVQ_FORCE_COLLECTIVE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.backend)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             if args.backend == "nccl":
                 dist.barrier(device_ids=[device.index])
             else:
@@ -359,20 +369,19 @@ def main():
     def step(prior=args.prior):
         if refiner is None:
             out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None,
-                               gather=world > 1, n_total=world * B, async_gather=not os.environ.get('DVQ_SYNC_GATHER'))
+                               gather=use_dist, n_total=world * B, async_gather=not os.environ.get('DVQ_SYNC_GATHER'))
             return out["vertices"]
         # generation, then the adaptation loop on this rank's grasps, then the final hand and the gather
         out = gen.generate(obj, first_id=first_id, x_tilde=forced if prior == "forced" else None)
         p = refiner.refine(obj, out["recon_param"])["recon_param"]
         verts = gen.rh_mano(global_orient=p[:, 10:13].contiguous(), hand_pose=p[:, 13:58].contiguous(),
                             transl=p[:, 58:].contiguous()).vertices
-        if world > 1:
-            from dvq_hip import parallel
+        if use_dist:
             verts = parallel.gather_rows(verts, world * B)
         return verts
 
     elapsed = timed_steps(step, args.steps, args.warmup, device, barrier, kernel_timers=True, finish=finish_gathers)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -383,13 +392,13 @@ def main():
     # The collective by itself: the same all-gather of one step's vertices with nothing beside it (in the timed
     # steps it runs beside the next step's kernels), max over ranks.
     gather_alone = None
-    if world > 1:
+    if use_dist:
         v = torch.randn((B, 778, 3), dtype=torch.float32, device=device)
         el = timed_steps(lambda: parallel.gather_rows(v, world * B), args.steps, 2, device, barrier)
         t = torch.tensor([el], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item()) / args.steps * 1e3
-        recv = (world - 1) * B * 778 * 3 * 4
+        recv = max(world - 1, 1 if args.force_dist else 0) * B * 778 * 3 * 4
         gather_alone = {"ms": round(ms, 4), "bytes_received_per_rank": recv, "GBs_received_per_rank": round(recv / ms / 1e6, 1),
                         "note": "all-gather of one step's vertices alone, synchronous, nothing else on the device"}
         del v
@@ -405,7 +414,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "end-to-end GenNet.gen (2 object encoders -> VQ -> prior -> decoder -> MANO -> hand "
                                    "encoder -> pos decoder) + call-site MANO LBS" +
-                                   (f" + {'RCCL' if args.backend == 'nccl' else args.backend} all-gather of vertices" if world > 1 else ""),
+                                   (f" + {'RCCL' if args.backend == 'nccl' else args.backend} all-gather of vertices" if use_dist else "") +
+                                   (" (one-rank process group: rehearsal of the multi-rank path)" if args.force_dist and world == 1 else ""),
                        "objects_per_gpu": B, "points_per_object": N, "global_batch": world * B,
                        "prior": args.prior,
                        "prior_note": "every grid is sampled in full each step; what depends on the class label alone (the "
@@ -422,7 +432,7 @@ def main():
         if roof_mano is not None:
             result["roofline_mano"] = roof_mano
 
-    if not args.no_extras and world == 1:
+    if not args.no_extras and world == 1 and not args.force_dist:
         # variants of the same step, the VQ microbench and the CPU baseline (rank 0, N=1 only)
         variants = {}
         other = "forced" if args.prior == "sampled" else "sampled"
@@ -472,7 +482,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         barrier()
         dist.destroy_process_group()
 

@@ -6,6 +6,7 @@ and nothing is exchanged while computing.  The only collective is the all-gather
 finished outputs (vertices, 9336 B per grasp): RCCL over xGMI when the process group is
 'nccl', gloo in the CPU tests and in the several-ranks-on-one-GPU rehearsal.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -77,7 +78,10 @@ def gather_rows(t: torch.Tensor, n_total: Optional[int] = None, async_op: bool =
     copy is issued here: the host collective itself runs inside work.wait(), so nothing overlaps, and a rank that
     drops its handle without waiting never enters the collective and hangs its peers."""
     rank, ws = world()
-    if ws == 1:
+    # (a world of one has nothing to exchange; with DVQ_FORCE_COLLECTIVE=1 and an initialised process group the
+    # collective is issued all the same: the one-rank rehearsal of the RCCL path on a box with a single GPU)
+    rehearse = ws == 1 and os.environ.get("DVQ_FORCE_COLLECTIVE") == "1" and dist.is_available() and dist.is_initialized()
+    if ws == 1 and not rehearse:
         out = t if n_total is None else t[:n_total]
         return (out, None) if async_op else out
     if n_total is not None:
