@@ -24,7 +24,10 @@ constexpr int S = 8;                       // k-steps of 32 dims: D = 256
 constexpr int NB = 4;                      // latent tiles per wave
 constexpr int GROUP_BYTES = (2 * S + 1) * 1024;
 constexpr int TS = 4;                      // groups per stage (68 KiB)
-constexpr int WAVES = 8;
+#ifndef CEIL_WAVES
+#define CEIL_WAVES 8
+#endif
+constexpr int WAVES = CEIL_WAVES;   // 8: two waves per SIMD (the search); 4: one wave per SIMD
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
