@@ -175,16 +175,24 @@ def read_grasp_json(path: str) -> Dict[str, np.ndarray]:
 
 
 def diverse_grasps(generator, obj_pc: torch.Tensor, n_grasps: int = 100, rng: Optional[np.random.RandomState] = None,
-                   first_id: int = 0, device=None) -> Tuple[Dict[str, list], torch.Tensor]:
+                   first_id: int = 0, device=None, refiner=None) -> Tuple[Dict[str, list], torch.Tensor]:
     """The body of the reference's per-object loop (gen_diverse_grasp_ho3d.py:212-257,315-318) as
     one batch: n_grasps random placements of obj_pc [4,N] -> gen -> parameter vector -> MANO.
     Returns (JSON-ready record, vertices [n,778,3] on the device).  `generator` is a
-    dvq_hip.pipeline.GraspGenerator; grasp i uses the sampling stream of object id first_id+i."""
+    dvq_hip.pipeline.GraspGenerator; grasp i uses the sampling stream of object id first_id+i.
+    With `refiner` (a dvq_hip.tta.GraspRefiner) every grasp is adapted to its cloud before it is recorded, as the
+    reference's adaptation script does between generation and the final hand (gen_HDMO_TTA.py:113-163)."""
     pl = random_placements(n_grasps, rng)
     clouds = place_clouds(obj_pc, pl["R"])
     dev = device if device is not None else next(generator.model.parameters()).device
-    out = generator.generate(clouds.to(dev), first_id=first_id)
-    return grasp_record(out["recon_param"], pl), out["vertices"]
+    clouds = clouds.to(dev)
+    out = generator.generate(clouds, first_id=first_id)
+    param, verts = out["recon_param"], out["vertices"]
+    if refiner is not None:
+        param = refiner.refine(clouds, param)["recon_param"]
+        verts = generator.rh_mano(betas=param[:, :10], global_orient=param[:, 10:13], hand_pose=param[:, 13:58],
+                                  transl=param[:, 58:]).vertices
+    return grasp_record(param, pl), verts
 
 
 def diversity(params: np.ndarray, cls_num: int = 20, seed: Optional[int] = None) -> Tuple[float, float]:

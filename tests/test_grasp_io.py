@@ -134,6 +134,31 @@ def test_diverse_grasps_batch_equals_one_call_per_placement():
         assert np.allclose(np.asarray(rec["recon_params"][i][0], dtype=np.float32), one["recon_param"][0].cpu().numpy(), atol=2e-5)
 
 
+@pytest.mark.gpu
+def test_diverse_grasps_with_adaptation_records_the_adapted_grasps():
+    """With a refiner the recorded parameters are the generated ones after the adaptation steps
+    (gen_HDMO_TTA.py:113-163) and the vertices returned are the hand of the recorded parameters."""
+    from dvq_hip import synth
+    from dvq_hip.pipeline import GraspGenerator
+    from dvq_hip.tta import GraspRefiner
+    dev = torch.device("cuda", 0)
+    gen = GraspGenerator.synthetic(dev, seed=0, dtype=torch.float32)
+    g = np.random.default_rng(2)
+    pc = grasp_io.make_obj_pc(g.uniform(-0.05, 0.05, size=(3000, 3)), 0.17)
+    plain, _ = grasp_io.diverse_grasps(gen, pc, n_grasps=4, rng=np.random.RandomState(5), first_id=40, device=dev)
+    refiner = GraspRefiner(gen.rh_mano, faces=synth.closed_hand_faces(0), iters=5)
+    rec, verts = grasp_io.diverse_grasps(gen, pc, n_grasps=4, rng=np.random.RandomState(5), first_id=40, device=dev, refiner=refiner)
+    p0 = torch.tensor(plain["recon_params"], dtype=torch.float32).reshape(4, 61)
+    p1 = torch.tensor(rec["recon_params"], dtype=torch.float32).reshape(4, 61)
+    pl = grasp_io.random_placements(4, np.random.RandomState(5))
+    clouds = grasp_io.place_clouds(pc, pl["R"]).to(dev)
+    want = refiner.refine(clouds, p0.to(dev))["recon_param"]
+    assert torch.allclose(p1, want.cpu(), rtol=0, atol=1e-6)
+    assert torch.equal(p1[:, :10], p0[:, :10])                              # shape coefficients are not adapted
+    hand = gen.rh_mano(global_orient=want[:, 10:13], hand_pose=want[:, 13:58], transl=want[:, 58:]).vertices
+    assert torch.allclose(verts, hand, rtol=0, atol=1e-6)
+
+
 def test_reader_and_placements_against_the_reference_stored_outputs():
     """tests/golden/hmdo_obj_id_0.json is one file the reference's generation script wrote
     (DVQ-VAE-2/diverse_grasp/HMDO/obj_id_0.json, gen_diverse_grasp_ho3d.py:322-331); mano_hmdo.npz holds the

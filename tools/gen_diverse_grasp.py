@@ -56,11 +56,22 @@ def main():
     ap.add_argument("--checkpoint", default="")
     ap.add_argument("--prior", default="./checkpoints/LATENT_BLOCK_pixelcnn.pt")
     ap.add_argument("--mano", default="./models/mano/MANO_RIGHT.pkl")
+    ap.add_argument("--tta-iters", type=int, default=0,
+                    help="adapt every generated grasp to its object with this many SGD steps before it is written "
+                         "(DVQ-VAE/gen_HDMO_TTA.py:119-152 uses 300); 0 = generation only")
+    ap.add_argument("--closed-faces", default="",
+                    help="closed hand mesh for the adaptation's vertex normals (the reference reads "
+                         "./models/mano/closed_mano_faces.pkl, gen_HDMO_TTA.py:61-62); default: the model's own faces")
     args = ap.parse_args()
 
     from dvq_hip import grasp_io
     device = torch.device("cuda", 0)
     gen = build_generator(args, device)
+    refiner = None
+    if args.tta_iters > 0:
+        from dvq_hip.tta import GraspRefiner, read_closed_faces
+        faces = read_closed_faces(args.closed_faces) if args.closed_faces else None
+        refiner = GraspRefiner(gen.rh_mano, faces=faces, iters=args.tta_iters)
     rs = np.random.RandomState(args.seed)
     for k, path in enumerate(args.objects):
         if path.endswith(".npy"):
@@ -68,7 +79,8 @@ def main():
             obj_pc = grasp_io.make_obj_pc(pts, grasp_io.get_diameter(pts))
         else:
             obj_pc, _, _ = grasp_io.obj_pc_from_mesh(path, seed=args.seed)
-        record, verts = grasp_io.diverse_grasps(gen, obj_pc, args.num_grasp, rs, first_id=k * args.num_grasp, device=device)
+        record, verts = grasp_io.diverse_grasps(gen, obj_pc, args.num_grasp, rs, first_id=k * args.num_grasp, device=device,
+                                                refiner=refiner)
         name = os.path.splitext(os.path.basename(path))[0]
         digits = "".join(ch for ch in name[:3] if ch.isdigit())
         out = os.path.join(args.out, f"obj_id_{int(digits)}.json" if len(digits) == 3 else f"obj_{name}.json")
