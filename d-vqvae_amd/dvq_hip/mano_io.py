@@ -341,12 +341,13 @@ def read_pickled_arrays(path: str):
     with open(path, "rb") as fh:
         data = fh.read()
     try:
-        tree = _tokens_to_tree(data)
+        return _interpret(_tokens_to_tree(data))
     except ModelFileError:
         raise
-    except Exception as e:                 # a truncated or corrupt stream: the tokeniser's own errors, index errors
-        raise ModelFileError(f"malformed model file: {e}") from None
-    return _interpret(tree)
+    except RecursionError:
+        raise ModelFileError("model file nests too deeply") from None
+    except Exception as e:                 # a truncated or corrupt stream: the tokeniser's own errors, index/type/value errors
+        raise ModelFileError(f"malformed model file: {type(e).__name__}: {e}") from None
 
 
 def read_model_file(path: str) -> dict:

@@ -258,6 +258,23 @@ def test_mano_file_reader_builds_arrays_and_refuses_code(tmp_path):
     import mano
     m = mano.load(str(path), use_pca=True, num_pca_comps=45, batch_size=1, flat_hand_mean=True)
     assert m.is_rhand and m.v_template.shape == (778, 3)
+    # damaged files: cut short or with flipped bytes, every outcome is either the arrays or ModelFileError -- no other
+    # exception, and nothing the bytes happen to name is ever looked up
+    small = pickle.dumps({k: (np.asarray(v)[:4] if isinstance(v, np.ndarray) else v) for k, v in blob_plain.items()}, protocol=2)
+    r = np.random.default_rng(0)
+    bad = tmp_path / "damaged.pkl"
+    for trial in range(300):
+        data = bytearray(small)
+        if trial % 3 == 0:
+            data = data[:int(r.integers(1, len(data)))]
+        else:
+            for _ in range(int(r.integers(1, 6))):
+                data[int(r.integers(0, len(data)))] = int(r.integers(0, 256))
+        bad.write_bytes(bytes(data))
+        try:
+            mano_io.read_pickled_arrays(str(bad))
+        except mano_io.ModelFileError:
+            pass
 
 
 def test_committed_bench_line_follows_the_contract():
