@@ -28,7 +28,7 @@ from dvq_hip import ops, parallel, synth  # noqa: E402
 from dvq_hip.pipeline import GraspGenerator  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X
-PMC_TRAFFIC_BYTES = 2.317e8                     # encoder trunk, 4096 x 3000 x C4 bf16: FETCH_SIZE x 2 + WRITE_SIZE per launch
+PMC_TRAFFIC_BYTES = 2.173e8                     # encoder trunk, 4096 x 3000 x C4 bf16: FETCH_SIZE x 2 + WRITE_SIZE per launch
 PEAK_HBM_GBS = 8000.0                           # HBM3E spec; a bare 16-B-per-lane read of 0.5 GB reaches 5.0-5.4 TB/s here
 PEAK_L2_LDS_GBS = 17500.0                       # L2 -> LDS gather rate the part sustains (16.8-18.8 TB/s measured)
 FLOP_PER_POINT = {3: 2 * (3 * 64 + 64 * 128 + 128 * 1024), 4: 2 * (4 * 64 + 64 * 128 + 128 * 1024)}
@@ -70,15 +70,15 @@ def encoder_roofline(N, dtype_name, traffic_note=True):
     peak = PEAK_TFLOPS[dtype_name]
     # HBM bytes per launch from the FETCH_SIZE (x2, the gfx950 correction for 16-B-per-lane streams) and WRITE_SIZE
     # counters: NOT measured by this run -- a constant from separate rocprofv3 --pmc passes over the same kernel and
-    # shape (profiles/r3c_pmc_fetch_write.txt; an earlier pass of the same kernel read 2.173e8); only valid for that
+    # shape (profiles/r3e_pmc_fetch_write.txt: 2.173e8; the pass on another box, r3c: 2.317e8); only valid for that
     # configuration
     traffic = PMC_TRAFFIC_BYTES if (kb, kc, kn, dtype_name) == (4096, 4, 3000, "bf16") else None
     out = {"bound": "mfma", "kernel": name + (" (v_mfma_f32_16x16x32_bf16)" if dtype_name == "bf16" else " (v_mfma_f32_32x32x2_f32)"),
            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
            "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches, "flop_per_launch": flops}
     if traffic is not None:
-        out["traffic_note"] = ("HBM bytes per launch from separate PMC passes (profiles/r3c_pmc_fetch_write.txt), not from this "
-                               "run; algorithmic bytes 2.134e8")
+        out["traffic_note"] = ("HBM bytes per launch from separate PMC passes (profiles/r3e_pmc_fetch_write.txt; r3c, another "
+                               "box: 2.317e8), not from this run; algorithmic bytes 2.134e8")
     return out
 
 
