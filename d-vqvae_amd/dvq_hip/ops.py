@@ -397,9 +397,10 @@ def mano_lbs(global_orient, hand_pose, transl, consts: DvqManoConsts, n_verts: i
             return 0
         if not t.is_cuda:
             raise RuntimeError("dvq_hip kernels need tensors on a HIP device (got a CPU tensor); there is no CPU fallback")
-        if t.dtype != torch.float32 or t.dim() != 2 or t.shape != (B, width) or (width > 1 and t.stride(1) != 1):
-            raise RuntimeError(f"mano_lbs: {what} must be float32 [B,{width}] with contiguous rows")
-        return max(int(t.stride(0)), width) if B > 1 else width
+        if t.dtype != torch.float32 or t.dim() != 2 or t.shape != (B, width) or (width > 1 and t.stride(1) != 1) \
+                or (B > 1 and t.stride(0) < width):
+            raise RuntimeError(f"mano_lbs: {what} must be float32 [B,{width}] with contiguous, non-overlapping rows")
+        return int(t.stride(0)) if B > 1 else width
     ld_go = rows(global_orient, 3, "global_orient")
     ld_hp = rows(hand_pose, consts.n_comps, "hand_pose")
     ld_tr = rows(transl, 3, "transl")

@@ -252,7 +252,9 @@ class MANO(nn.Module):
             """float32 with contiguous rows: a column range of a wider buffer (the call sites' slices of the 61-d
             parameter vector) is passed to the kernel as it is, anything else is copied."""
             t = keep(t).to(torch.float32)
-            return t if (t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1) and not want_grad) else t.contiguous()
+            in_place = (t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1) and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1])
+                        and not want_grad)          # (an expanded row has stride 0: copied)
+            return t if in_place else t.contiguous()
         hp = as_rows(hand_pose)
         go = as_rows(global_orient)
         B = hp.shape[0]

@@ -295,6 +295,13 @@ def test_mano_reads_column_ranges_of_the_parameter_vector_in_place(B):
     z = torch.zeros(B, 3, device=DEV)
     assert torch.equal(rh.hip_vertices(param[:, 13:58]), rh(global_orient=z, hand_pose=hp.to(DEV), transl=z).vertices)
     assert torch.equal(rh.hip_vertices(param[:, 13:58], param[:, 10:13], param[:, 58:]), b.vertices)
+    # a broadcast row (stride 0) is not a column range: it is copied, not read past its end
+    one = torch.zeros(1, 3, device=DEV)
+    assert torch.equal(rh(global_orient=one.expand(B, 3), hand_pose=hp.to(DEV), transl=one.expand(B, 3)).vertices,
+                       rh(global_orient=z, hand_pose=hp.to(DEV), transl=z).vertices)
+    if B > 1:
+        with pytest.raises(RuntimeError):
+            ops.mano_lbs(one.expand(B, 3), hp.to(DEV), None, rh._device_consts(), 778)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
