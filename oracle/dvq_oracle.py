@@ -63,6 +63,22 @@ def vq_forward(z: torch.Tensor, E: torch.Tensor) -> Tuple[torch.Tensor, torch.Te
     return idx, z_q
 
 
+def vq_forward_train(z: torch.Tensor, E: torch.Tensor, beta: float, al: float):
+    """quantizer.py:35-43, 56-67 (istrain=True): (loss, straight-through z_q, perplexity, one-hot rows, idx).
+    z and E may require gradients: the loss reaches z through its first term and E through the second, z_q passes
+    its cotangent to z alone."""
+    d = vq_distances(z, E)
+    idx = torch.argmin(d, dim=1).unsqueeze(1)
+    onehot = torch.zeros(idx.shape[0], E.shape[0])
+    onehot.scatter_(1, idx, 1)
+    z_q = torch.matmul(onehot, E).view(z.shape)
+    loss = al * torch.mean((z_q.detach() - z) ** 2) + beta * torch.mean((z_q - z.detach()) ** 2)
+    z_q = z + (z_q - z).detach()
+    e_mean = torch.mean(onehot, dim=0)
+    perplexity = torch.exp(-torch.sum(e_mean * torch.log(e_mean + 1e-10)))
+    return loss, z_q, perplexity, onehot, idx
+
+
 def vq_get_emb(idx: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
     """quantizer.py:68-75 generalised to a batch: row b equals the reference's
     get_emb(idx[b:b+1], dim) (the reference only accepts one index per call)."""

@@ -163,6 +163,42 @@ def golden_vq_near_ties(ref):
     save("vq_near", **out)
 
 
+VQ_TRAIN_CASES = [(128, 256, 96), (128, 1024, 24)]
+
+
+def vq_train_weights(n, D):
+    """The fixed cotangent of z_q in the training-mode fixture (regenerated by the tests from the same seed)."""
+    return torch.randn(n, D, generator=torch.Generator().manual_seed(11))
+
+
+def golden_vq_train(ref):
+    """Training-mode outputs of the reference: VQVAE.forward (VQVAE.py:29-42) -> (loss, straight-through z_q,
+    perplexity), the quantizer's own five outputs (quantizer.py:35-43, 56-67: one-hot rows stored as column sums, and
+    indices), and the gradients of  loss + <z_q, w>  with respect to the latents and the codebook.  Latents and codebook
+    are regenerated from the seed (synth.vq_case 'B', seed 5), w by vq_train_weights."""
+    import network.VQVAE as vw
+    out = {}
+    for K, D, n in VQ_TRAIN_CASES:
+        z, E = synth.vq_case(K, D, n, "B", seed=5)
+        w = vq_train_weights(n, D)
+        model = vw.VQVAE(0, 0, 0, K, D, 0.25, a=1)
+        model.vector_quantization.embedding.weight.data.copy_(E)
+        zr = z.clone().requires_grad_(True)
+        loss, zq, perp = model(zr)
+        (loss + (zq * w).sum()).backward()
+        with torch.no_grad():
+            loss5, zq5, perp5, onehot, idx = model.vector_quantization(z, True)
+        assert torch.equal(loss5, loss) and torch.equal(zq5, zq) and torch.equal(perp5, perp)
+        assert tuple(onehot.shape) == (n, K) and tuple(idx.shape) == (n, 1) and torch.equal(onehot.argmax(1), idx[:, 0])
+        out[f"loss_{K}_{D}"] = loss.detach().numpy()
+        out[f"zq_{K}_{D}"] = zq.detach().numpy()
+        out[f"perplexity_{K}_{D}"] = perp.detach().numpy()
+        out[f"idx_{K}_{D}"] = idx[:, 0].numpy().astype(np.int32)
+        out[f"dz_{K}_{D}"] = zr.grad.numpy()
+        out[f"dE_{K}_{D}"] = model.vector_quantization.embedding.weight.grad.numpy()
+    save("vq_train", **out)
+
+
 def real_clouds():
     """The four object clouds bundled with the reference ((3000,3) float64 .npy, plain
     arrays): used as realistic encoder inputs with the dataset's 4-channel layout
@@ -390,7 +426,7 @@ def golden_dvqvae(ref):
     save("dvqvae", f0hand=np.array(f0, np.int32), hand_xyz=hand, emb_idx=emb_idx, obj_emb=obj_emb)
 
 
-STEPS = ("vq", "vq_near_ties", "pointnet", "mlp", "mano", "mano_hmdo", "dvqvae", "gen")
+STEPS = ("vq", "vq_near_ties", "vq_train", "pointnet", "mlp", "mano", "mano_hmdo", "dvqvae", "gen")
 
 
 def main():

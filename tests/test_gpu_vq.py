@@ -111,6 +111,34 @@ def test_vq_ties_pick_lowest_index_and_odd_K():
     check_vq_rows(z, E, idx.cpu().numpy(), ref[:, 0].numpy())
 
 
+@pytest.mark.parametrize("K,D,n", [(128, 256, 96), (128, 1024, 24)])
+def test_vqvae_training_mode_vs_reference_golden(K, D, n):
+    """VQVAE.forward -> (loss, z_q, perplexity) and the quantizer's five training-mode outputs (VQVAE.py:29-42,
+    quantizer.py:35-43, 56-67) with the search on the HIP kernel: indices equal to the reference's, values and the
+    gradients of loss + <z_q, w> with respect to latents and codebook within 1e-6 relative (fp32 sums in another order)."""
+    from network.VQVAE import VQVAE
+    g = load_golden("vq_train")
+    z, E = synth.vq_case(K, D, n, "B", seed=5)
+    w = torch.randn(n, D, generator=torch.Generator().manual_seed(11)).to(DEV)
+    model = VQVAE(0, 0, 0, K, D, 0.25, a=1).to(DEV)
+    model.vector_quantization.embedding.weight.data.copy_(E)
+    zr = z.to(DEV).requires_grad_(True)
+    loss, zq, perp = model(zr)
+    (loss + (zq * w).sum()).backward()
+    loss5, zq5, perp5, onehot, idx = model.vector_quantization(zr.detach(), True)
+    assert idx.dtype == torch.int64 and tuple(idx.shape) == (n, 1) and tuple(onehot.shape) == (n, K)
+    assert np.array_equal(idx[:, 0].cpu().numpy(), g[f"idx_{K}_{D}"])
+    assert torch.equal(onehot.argmax(1), idx[:, 0]) and float(onehot.sum()) == n
+    assert torch.equal(zq5, zq.detach()) and torch.equal(loss5.detach(), loss.detach()) and torch.equal(perp5, perp)
+
+    def close(name, got):
+        ref = g[f"{name}_{K}_{D}"]
+        err = np.abs(got.detach().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert err <= 1e-6, (name, err)
+    close("loss", loss); close("zq", zq); close("perplexity", perp)
+    close("dz", zr.grad); close("dE", model.vector_quantization.embedding.weight.grad)
+
+
 def test_vq_prepared_matches_one_shot_and_gather():
     z, E = synth.vq_case(512, 256, 2000, "B", seed=9)
     zd, Ed = z.to(DEV), E.to(DEV)

@@ -36,6 +36,30 @@ def test_vq_ragged_and_ties():
     assert np.array_equal(O.vq_get_emb(torch.tensor([9]), E).numpy(), g["get_emb_9"])
 
 
+VQ_TRAIN_CASES = [(128, 256, 96), (128, 1024, 24)]     # as in tests/golden/make_golden.py
+
+
+def vq_train_case(K, D, n):
+    z, E = synth.vq_case(K, D, n, "B", seed=5)
+    w = torch.randn(n, D, generator=torch.Generator().manual_seed(11))
+    return z, E, w
+
+
+@pytest.mark.parametrize("K,D,n", VQ_TRAIN_CASES)
+def test_vq_training_mode_vs_reference_golden(K, D, n):
+    """quantizer.py:35-43, 56-67 through VQVAE.forward (VQVAE.py:29-42): loss, straight-through z_q, perplexity,
+    indices, and the gradients of loss + <z_q, w> with respect to latents and codebook."""
+    g = load_golden("vq_train")
+    z, E, w = vq_train_case(K, D, n)
+    zr, Er = z.clone().requires_grad_(True), E.clone().requires_grad_(True)
+    loss, zq, perp, onehot, idx = O.vq_forward_train(zr, Er, 0.25, 1)
+    (loss + (zq * w).sum()).backward()
+    assert np.array_equal(idx[:, 0].numpy(), g[f"idx_{K}_{D}"])
+    assert np.array_equal(onehot.argmax(1).numpy(), g[f"idx_{K}_{D}"]) and float(onehot.sum()) == n
+    for name, got in (("loss", loss), ("zq", zq), ("perplexity", perp), ("dz", zr.grad), ("dE", Er.grad)):
+        assert np.array_equal(got.detach().numpy(), g[f"{name}_{K}_{D}"]), name
+
+
 @pytest.mark.parametrize("K,D", [(128, 256), (512, 256)])
 @pytest.mark.parametrize("kind", ["mid", "bignorm"])
 def test_vq_oracle_vs_reference_on_near_ties(K, D, kind):
