@@ -1,4 +1,4 @@
-# One GPU call that produces a round-3 profile set under gpurun_out/$1 (default r3c): GPU tests, smoke(), the bench line with the
+# One GPU call that produces a profile set under gpurun_out/$1 (default r3c): GPU tests, smoke(), the bench line with the
 # driver's flags, the bench under rocprofv3 --kernel-trace --stats (kernel statistics; per-launch rows of the object encoder in both
 # precisions and of the hand layer), the launch timeline of one step, FETCH_SIZE / WRITE_SIZE of the HBM-facing kernels
 # (one --pmc pass each) and the two-rank gloo rehearsal of `bench.py --gpus 2` on the one GPU.
