@@ -5,6 +5,26 @@
 """
 import torch
 
+_weights_epoch = 0
+
+
+def weights_epoch() -> int:
+    """Counter that every module mixes into the key of its packed (kernel-layout) copy of its weights."""
+    return _weights_epoch
+
+
+def weights_changed() -> None:
+    """Tell the modules that weights were edited behind autograd's back.
+
+    Every module keeps a packed copy of its weights (folded BatchNorm, MFMA fragment order, bf16 copies, the prior's
+    per-class tables, the hand model's tables) and rebuilds it when a parameter or buffer has another address or another
+    `_version`.  In-place edits through `tensor.data` -- `w.data.copy_(...)`, `w.data.uniform_()`, the idiom of the
+    reference's own initialisers (quantizer.py:27, pixelcnn/models.py:11-18) -- do not move `_version`, so after such an
+    edit of a model that has already run, call this once: every packed copy in the process is rebuilt on its next use.
+    `load_state_dict`, optimizer steps, `.to(...)` and in-place operations on the parameter itself are seen without it."""
+    global _weights_epoch
+    _weights_epoch += 1
+
 
 def set_compute_dtype(model, dtype):
     """Select exact-fp32 (torch.float32) or bf16-operand (torch.bfloat16) matrix-core

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import dvq_hip
 from dvq_hip import ops
 from dvq_hip._lib import DvqManoConsts
 from dvq_hip.mano_io import Struct, read_model_file, to_np
@@ -197,7 +198,7 @@ class MANO(nn.Module):
                    self.pose_mean, self.parents] + ([self.hand_components] if self.use_pca else [])
         if hasattr(self, 'betas'):
             tensors.append(self.betas)
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        key = (dvq_hip.weights_epoch(),) + tuple((t.data_ptr(), t._version) for t in tensors)
         if key != self._consts_key:
             dev = self.v_template.device
             with torch.no_grad():

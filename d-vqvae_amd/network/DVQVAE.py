@@ -12,6 +12,7 @@ set used here is the documented reconstruction in dvq_hip.hand_parts.
 import torch
 import torch.nn as nn
 
+import dvq_hip
 from dvq_hip import ops
 from dvq_hip._lib import DVQ_BF16, DVQ_F32
 from dvq_hip.hand_parts import HAND_PARTS
@@ -22,7 +23,7 @@ from network.VQVAE import VQVAE
 def _bf16_weight(layer):
     """bf16 copy of an nn.Linear's weight, kept on the layer and refreshed when the weight changes."""
     W = layer.weight.detach()
-    key = (W.data_ptr(), W._version)
+    key = (W.data_ptr(), W._version, dvq_hip.weights_epoch())
     if getattr(layer, "_dvq_bf16_key", None) != key:
         layer._dvq_bf16 = ops.to_bf16(W)
         layer._dvq_bf16_key = key
@@ -82,7 +83,7 @@ class Decoder(nn.Module):
             W0, W1 = layers[0].weight.detach(), layers[1].weight.detach()
             # packed weights per split of the input into pieces (forward(z) brings one piece, gen() seven): callers that
             # alternate between splits do not re-pack; a new weight version drops them all
-            wkey = (W0.data_ptr(), W0._version, W1.data_ptr(), W1._version)
+            wkey = (W0.data_ptr(), W0._version, W1.data_ptr(), W1._version, dvq_hip.weights_epoch())
             if getattr(self, "_head_wkey", None) != wkey:
                 self._heads, self._head_wkey = {}, wkey
             head = self._heads.get(tuple(widths))

@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import dvq_hip
 from dvq_hip import ops
 from dvq_hip._lib import DVQ_BF16, DVQ_F32
 from dvq_hip.rng import sample_rows
@@ -174,7 +175,7 @@ class GatedPixelCNN(nn.Module):
         raise RuntimeError(f"GatedPixelCNN: compute_dtype {self.compute_dtype} (float32 or bfloat16 expected)")
 
     def _weights_key(self):
-        return (tuple((p.data_ptr(), p._version) for p in self.parameters()), self._code())
+        return ((dvq_hip.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in self.parameters()), self._code())
 
     def _prepared_hip(self):
         key = self._weights_key()

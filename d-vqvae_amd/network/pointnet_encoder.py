@@ -15,12 +15,13 @@ dvq_hip.set_compute_dtype(model, dtype).
 import torch
 import torch.nn as nn
 
+import dvq_hip
 from dvq_hip import ops
 from dvq_hip._lib import DVQ_BF16, DVQ_F32
 
 
 def _version_key(module):
-    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+    return (dvq_hip.weights_epoch(),) + tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
 
 
 def _fold(conv_or_fc, bn):
@@ -161,7 +162,7 @@ class PointNetEncoder(nn.Module):
 
     def _packed(self):
         own = [self.conv1, self.conv2, self.conv3, self.bn1, self.bn2, self.bn3]
-        key = (tuple(k for m in own for k in _version_key(m)), self.compute_dtype)
+        key = (tuple(_version_key(m) for m in own), self.compute_dtype)
         if key != self._cache_key:
             self._cache = _Trunk(self, _dtype_code(self.compute_dtype))
             self._cache_key = key

@@ -10,6 +10,7 @@ accepts any number of indices (the reference only one, quantizer.py:72-74).
 import torch
 import torch.nn as nn
 
+import dvq_hip
 from dvq_hip import ops
 
 
@@ -27,7 +28,7 @@ class VectorQuantizer(nn.Module):
 
     def _prepared(self):
         w = self.embedding.weight
-        key = (w.data_ptr(), w._version, w.device, w.dtype)
+        key = (w.data_ptr(), w._version, w.device, w.dtype, dvq_hip.weights_epoch())
         if self._prep_key != key:
             self._prep = ops.vq_prepare(w.detach())
             self._prep_key = key

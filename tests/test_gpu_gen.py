@@ -479,3 +479,37 @@ def test_gen_byid_decodes_the_zero_latent():
     many, pos_many = model.gen_byid(torch.tensor([3, 4, 5], device=DEV))
     assert many.shape == (3, 55) and pos_many.shape == (3, 6)
     assert torch.equal(many, recon.expand(3, -1))
+
+
+def test_weight_edits_through_data_are_picked_up_after_weights_changed():
+    """In-place edits through `.data` (the reference's own initialiser idiom, quantizer.py:27) do not move a tensor's
+    version, so the modules' packed copies cannot see them: dvq_hip.weights_changed() makes every module repack.
+    Checked on every kind of packed copy of the generation path: encoder trunks and heads, codebook, prior, decoder
+    heads, hand model."""
+    import dvq_hip
+    model, rh = build()
+    objs = synth.object_clouds(3, 3000, seed=5).to(DEV)
+    xt = torch.randint(0, 128, (3, 3, 3), device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    fresh, rh2 = build()                                       # the same edits on a model that has not run yet
+    edits = [lambda m: m.obj_encoder_type.conv3.weight.data.mul_(1.25),
+             lambda m: m.obj_encoder_pos.stn.fc1.weight.data.mul_(0.5),
+             lambda m: m.vqvae6.vector_quantization.embedding.weight.data.neg_(),
+             lambda m: m.decoder.MLP.L0.weight.data.mul_(1.5),
+             lambda m: m.pos_decoder.MLP.L2.bias.data.add_(0.01),
+             lambda m: m.rh_mano.v_template.data.mul_(1.1)]
+    before = model.gen(objs, x_tilde=xt)
+    for e in edits:
+        e(model); e(fresh)
+    prior = next(m for m in model.modules() if type(m).__name__ == "GatedPixelCNN")
+    prior_fresh = next(m for m in fresh.modules() if type(m).__name__ == "GatedPixelCNN")
+    prior.output_conv[2].weight.data.mul_(0.5); prior_fresh.output_conv[2].weight.data.mul_(0.5)
+    dvq_hip.weights_changed()
+    after, want = model.gen(objs, x_tilde=xt), fresh.gen(objs, x_tilde=xt)
+    assert torch.equal(model.last_idx6, fresh.last_idx6)
+    assert torch.equal(after[0], want[0]) and torch.equal(after[1], want[1])
+    assert not torch.equal(after[0], before[0]) and not torch.equal(after[1], before[1])
+    lab = model.last_idx6[:, 0]
+    with torch.no_grad():                                      # (the HIP forward; with autograd on it is stock convolutions)
+        assert torch.equal(prior(xt, lab), prior_fresh(xt, lab))
+    hp = torch.randn(3, 45, device=DEV)
+    assert torch.equal(model.rh_mano.hip_vertices(hp), fresh.rh_mano.hip_vertices(hp))
