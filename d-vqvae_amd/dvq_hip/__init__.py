@@ -26,6 +26,20 @@ def weights_changed() -> None:
     _weights_epoch += 1
 
 
+class DropsPackedCopies:
+    """Mixin for modules that keep packed copies of their weights, launch buffers or recorded graphs: `_packed_defaults`
+    maps each such attribute to a factory of its empty value, and pickles and deep copies of the module carry the empty
+    values (the copies hold device addresses, ctypes structures and HIP graphs; all are rebuilt on the next use)."""
+    _packed_defaults = {}
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for name, empty in self._packed_defaults.items():
+            if name in state:
+                state[name] = empty()
+        return state
+
+
 def set_compute_dtype(model, dtype):
     """Select exact-fp32 (torch.float32) or bf16-operand (torch.bfloat16) matrix-core
     arithmetic for every PointNet encoder and MLP head inside `model` (the heads switch to bf16 operands only for

@@ -96,7 +96,8 @@ def lane_ordered_posedirs(posedirs, V):
     return padded[feat, vert].contiguous()
 
 
-class MANO(nn.Module):
+class MANO(dvq_hip.DropsPackedCopies, nn.Module):
+    _packed_defaults = {"_consts_key": lambda: None, "_consts": lambda: None}
     NUM_BODY_JOINTS = 1
     NUM_HAND_JOINTS = 15
     NUM_JOINTS = NUM_BODY_JOINTS + NUM_HAND_JOINTS

@@ -57,7 +57,9 @@ class Encoder(nn.Module):
         return _linear(self.linear_means, x, out=out, bf16=bf16)
 
 
-class Decoder(nn.Module):
+class Decoder(dvq_hip.DropsPackedCopies, nn.Module):
+    _packed_defaults = {"_heads": dict, "_head_wkey": lambda: None}
+
     def __init__(self, layer_sizes, latent_size):
         super().__init__()
         self.MLP = nn.Sequential()
@@ -109,7 +111,9 @@ class Decoder(nn.Module):
         return x
 
 
-class DVQVAE(nn.Module):
+class DVQVAE(dvq_hip.DropsPackedCopies, nn.Module):
+    _packed_defaults = {"_part_tab": lambda: None}
+
     def __init__(self, obj_inchannel=4):
         super().__init__()
         self.obj_inchannel = obj_inchannel

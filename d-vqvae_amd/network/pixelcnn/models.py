@@ -106,7 +106,9 @@ class _PackedTaps:
         self.mask_a = layer.mask_type == 'A'
 
 
-class GatedPixelCNN(nn.Module):
+class GatedPixelCNN(dvq_hip.DropsPackedCopies, nn.Module):
+    _packed_defaults = {"_packed_key": lambda: None, "_packed": lambda: None, "_bufs": dict, "_cls": lambda: None}
+
     def __init__(self, input_dim=256, dim=128, n_layers=15, n_classes=128):
         super().__init__()
         self.dim = dim

@@ -64,7 +64,9 @@ def _check_input(module, x, channel):
     return x.contiguous()
 
 
-class STN3d(nn.Module):
+class STN3d(dvq_hip.DropsPackedCopies, nn.Module):
+    _packed_defaults = {"_cache_key": lambda: None, "_cache": lambda: None, "_head": lambda: None}
+
     def __init__(self, channel):
         super().__init__()
         self.channel = channel
@@ -141,7 +143,9 @@ class STNkd(nn.Module):
         raise NotImplementedError("STNkd (feature_transform=True) is not on the generation path and has no HIP kernel")
 
 
-class PointNetEncoder(nn.Module):
+class PointNetEncoder(dvq_hip.DropsPackedCopies, nn.Module):
+    _packed_defaults = {"_cache_key": lambda: None, "_cache": lambda: None}
+
     def __init__(self, global_feat=True, feature_transform=False, channel=3):
         super().__init__()
         self.channel = channel

@@ -14,7 +14,9 @@ import dvq_hip
 from dvq_hip import ops
 
 
-class VectorQuantizer(nn.Module):
+class VectorQuantizer(dvq_hip.DropsPackedCopies, nn.Module):
+    _packed_defaults = {"_prep": lambda: None, "_prep_key": lambda: None}
+
     def __init__(self, n_e, e_dim, beta, al):
         super().__init__()
         self.n_e = n_e

@@ -513,3 +513,33 @@ def test_weight_edits_through_data_are_picked_up_after_weights_changed():
         assert torch.equal(prior(xt, lab), prior_fresh(xt, lab))
     hp = torch.randn(3, 45, device=DEV)
     assert torch.equal(model.rh_mano.hip_vertices(hp), fresh.rh_mano.hip_vertices(hp))
+
+
+def test_used_model_can_be_deep_copied_and_pickled(tmp_path):
+    """A model that has run holds packed weights, device buffers, ctypes tables and a recorded HIP graph; copies and
+    pickles carry none of them and rebuild their own on first use."""
+    import copy
+    import pickle
+    model, rh = build()
+    objs = synth.object_clouds(3, 3000, seed=8).to(DEV)
+    xt = torch.randint(0, 128, (3, 3, 3), device=DEV, generator=torch.Generator(DEV).manual_seed(2))
+    want = model.gen(objs, x_tilde=xt)
+    prior = next(m for m in model.modules() if type(m).__name__ == "GatedPixelCNN")
+    lab = model.last_idx6[:, 0].contiguous()
+    u = torch.rand(3, 9, dtype=torch.float64, device=DEV)
+    grids = [prior.generate(None, lab, shape=(3, 3), batch_size=3, uniforms=u).clone() for _ in range(3)][-1]   # (records the graph)
+    assert prior._packed is not None and model.rh_mano._consts is not None
+    twin = copy.deepcopy(model)
+    assert twin.rh_mano._consts is None and next(m for m in twin.modules() if type(m).__name__ == "GatedPixelCNN")._packed is None
+    got = twin.gen(objs, x_tilde=xt)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    with open(tmp_path / "model.pkl", "wb") as f:
+        pickle.dump(model, f)
+    with open(tmp_path / "model.pkl", "rb") as f:       # (a file this test wrote itself)
+        back = pickle.load(f)
+    got = back.gen(objs, x_tilde=xt)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    hp = torch.randn(3, 45, device=DEV)
+    assert torch.equal(back.rh_mano.hip_vertices(hp), model.rh_mano.hip_vertices(hp))
+    twin_prior = next(m for m in back.modules() if type(m).__name__ == "GatedPixelCNN")
+    assert torch.equal(twin_prior.generate(None, lab, shape=(3, 3), batch_size=3, uniforms=u), grids)
