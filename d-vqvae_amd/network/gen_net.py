@@ -68,6 +68,10 @@ class GenNet(nn.Module):
         if self.rh_mano is None:
             raise RuntimeError("GenNet.gen: call set_rh_mano(mano_layer) first")
         B = obj.size()[0]
+        if B == 0:                                  # an empty batch decodes to nothing
+            self.last_x_tilde = torch.zeros((0, 3, 3), dtype=torch.int64, device=obj.device)
+            self.last_idx6 = torch.zeros((0, 1), dtype=torch.int64, device=obj.device)
+            return torch.zeros((0, 55), device=obj.device), torch.zeros((0, 6), device=obj.device)
         together = B < self.together_below and obj.is_cuda
         if together:
             # small batches: both object encoders stage by stage in grouped launches (each launch alone would leave

@@ -246,6 +246,10 @@ class GatedPixelCNN(dvq_hip.DropsPackedCopies, nn.Module):
         dev = self.embedding.weight.device
         if not self.embedding.weight.is_cuda:
             raise RuntimeError("GatedPixelCNN.generate needs the module on a HIP device (there is no CPU path)")
+        if B == 0:                                 # an empty batch (a rank without objects): nothing to draw
+            n_out = self.output_conv[2].out_channels
+            empty = torch.zeros((0, H, W), dtype=torch.int64, device=dev)
+            return (empty, torch.zeros((0, H * W, n_out), dtype=torch.float32, device=dev)) if return_probs else empty
         self._prepared_hip()
         bufs = self._act_buffers(B, H, W, dev)
         n_classes = self.layers[0].class_cond_embedding.num_embeddings

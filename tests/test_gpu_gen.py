@@ -543,3 +543,33 @@ def test_used_model_can_be_deep_copied_and_pickled(tmp_path):
     assert torch.equal(back.rh_mano.hip_vertices(hp), model.rh_mano.hip_vertices(hp))
     twin_prior = next(m for m in back.modules() if type(m).__name__ == "GatedPixelCNN")
     assert torch.equal(twin_prior.generate(None, lab, shape=(3, 3), batch_size=3, uniforms=u), grids)
+
+
+def test_empty_and_odd_batches_through_the_modules():
+    """A rank without objects calls gen() with an empty batch; callers also bring float64 clouds, other point counts, and
+    the wrong channel count or device must raise instead of reading out of bounds."""
+    model, rh = build()
+    objs = synth.object_clouds(2, 3000, seed=4).to(DEV)
+    recon, pos = model.gen(objs[:0])
+    assert tuple(recon.shape) == (0, 55) and tuple(pos.shape) == (0, 6) and tuple(model.last_idx6.shape) == (0, 1)
+    prior = next(m for m in model.modules() if type(m).__name__ == "GatedPixelCNN")
+    lab0 = torch.zeros(0, dtype=torch.int64, device=DEV)
+    assert tuple(prior.generate(None, lab0, shape=(3, 3), batch_size=0).shape) == (0, 3, 3)
+    x0, p0 = prior.generate(None, lab0, shape=(3, 3), batch_size=0, return_probs=True)
+    assert tuple(x0.shape) == (0, 3, 3) and p0.shape[:2] == (0, 9)
+    f, t, _ = model.obj_encoder_type(objs[:0])
+    assert tuple(f.shape) == (0, 1024) and tuple(t.shape) == (0, 3, 3)
+    assert tuple(rh(global_orient=torch.zeros(0, 3, device=DEV), hand_pose=torch.zeros(0, 45, device=DEV),
+                    transl=torch.zeros(0, 3, device=DEV)).vertices.shape) == (0, 778, 3)
+    xt = torch.randint(0, 128, (2, 3, 3), device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    a = model.gen(objs, x_tilde=xt)
+    b = model.gen(objs.double(), x_tilde=xt)                 # float64 clouds are taken as float32
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    long_cloud = synth.object_clouds(1, 20001, seed=6).to(DEV)  # any point count
+    f_long, _, _ = model.obj_encoder_type(long_cloud)
+    ref, _ = O.pointnet_encoder(long_cloud.cpu(), {k: v.cpu() for k, v in model.state_dict().items()}, "obj_encoder_type.")
+    assert rel_err(f_long, ref) <= 1e-5
+    with pytest.raises(RuntimeError):
+        model.gen(objs[:, :3].contiguous())
+    with pytest.raises(RuntimeError):
+        model.gen(objs.cpu())
