@@ -157,7 +157,7 @@ class GraspRefiner:
         for b in st["buf"]:
             b.zero_()
         first = last = None
-        if iters > 0:
+        if iters > 0 and B > 0:        # (an empty batch -- a rank without objects -- has nothing to adapt or record)
             if self.use_graph and st["graph"] is None and iters > 2:
                 saved = [t.clone() for t in st["p"] + st["buf"]]
                 self._step(st)                                   # warm-up outside capture
@@ -178,6 +178,8 @@ class GraspRefiner:
                 if it == 0:
                     first = st["losses"].clone()
             last = st["losses"].clone()
+        elif iters > 0:
+            first, last = st["losses"].clone(), st["losses"].clone()      # [0,2]
         out = param.clone()
         out[:, 10:13], out[:, 13:58], out[:, 58:61] = st["p"]
         return dict(recon_param=out, first=first, last=last)

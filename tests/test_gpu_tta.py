@@ -234,3 +234,19 @@ def test_refiner_refuses_cpu_tensors(dev, hand):
     param, obj, obj_pc = _scene(sd, 1, seed=1)
     with pytest.raises(RuntimeError):
         GraspRefiner(rh).refine(obj_pc, param)
+
+
+def test_refiner_with_an_empty_batch_and_with_no_steps(dev, hand):
+    """A rank without objects hands the loop an empty batch: nothing is launched or recorded, shapes are kept.
+    iters = 0 returns the parameters as they came and no loss values."""
+    from dvq_hip.tta import GraspRefiner
+    rh, sd = hand
+    param, obj, obj_pc = _scene(sd, 2, seed=2)
+    r = GraspRefiner(rh, iters=4)
+    for _ in range(2):
+        out = r.refine(obj_pc[:0].to(dev), param[:0].to(dev))
+        assert tuple(out["recon_param"].shape) == (0, 61) and tuple(out["first"].shape) == (0, 2) and tuple(out["last"].shape) == (0, 2)
+    out = r.refine(obj_pc.to(dev), param.to(dev), iters=0)
+    assert torch.equal(out["recon_param"].cpu(), param) and out["first"] is None and out["last"] is None
+    moved = r.refine(obj_pc.to(dev), param.to(dev))             # the same refiner still works on a real batch afterwards
+    assert tuple(moved["first"].shape) == (2, 2) and not torch.equal(moved["recon_param"].cpu(), param)
