@@ -17,8 +17,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC between the ranks of a node: the host driver here supports no other, and without it RCCL fails with
+# "hipIpcGetMemHandle: invalid argument".  The launcher's environment normally carries this already.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "d-vqvae_amd"))
@@ -322,6 +326,13 @@ def main():
                          "(RCCL refuses two ranks per device)")
     args = ap.parse_args()
 
+    # ONE line on stdout: libraries write there too (RCCL prints a version banner when a communicator is created, gloo its
+    # connection notes), so everything but the result line goes to stderr -- file descriptor 1 is pointed at stderr for
+    # the run and the result is written to the original one at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -481,7 +492,9 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args.prior == "sampled")
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        with os.fdopen(result_fd, "w") as out:
+            out.write(json.dumps(result) + "\n")
     if use_dist:
         barrier()
         dist.destroy_process_group()
